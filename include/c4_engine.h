@@ -1,0 +1,203 @@
+/*
+ * c4_engine.h -- C ABI of the MI355X-native Connect4 self-play / MCTS engine (libc4engine.so).
+ *
+ * This is the drop-in boundary for the hot path of willis-richard/connect4 (`oinkoink`).  The
+ * reference has no FFI: its seam is two duck-typed Python protocols.  Each
+ * entry point below names the reference interface it stands in for (file:line relative to the
+ * reference root).  Host code (Python ctypes in connect4_amd/_lib.py, or any cgo/JNI/ctypes binding,
+ * see INTEGRATION.md) calls ONLY these functions; no HIP, torch or C++ types cross the boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative C4_E* code; nothing throws across the ABI;
+ *     c4_last_error() returns a static/engine-owned message for the last failure;
+ *   - the engine owns all tree memory in HBM; the caller owns I/O buffers and keeps them alive
+ *     until the stream has been synchronised;
+ *   - pointers named *_dev are DEVICE pointers (e.g. torch.Tensor.data_ptr()); all others are host;
+ *   - one engine per GPU per process, one host thread drives a handle (mirrors "one player serves
+ *     one game at a time", game_pool.py:29-32,45-49);
+ *   - there is NO CPU backend: creating an engine without a usable gfx950 device fails loudly.
+ */
+#ifndef C4_ENGINE_H
+#define C4_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C4_ABI_VERSION 1
+
+/* error codes */
+#define C4_OK 0
+#define C4_EINVAL (-1)   /* bad argument */
+#define C4_EDEVICE (-2)  /* no usable HIP device / HIP call failed */
+#define C4_ENOMEM (-3)
+#define C4_ESTATE (-4)   /* call not valid in the current engine state */
+#define C4_ECAPACITY (-5)
+
+/* Result codes (utils.py:19-22): value = code * 0.5 */
+#define C4_RESULT_NONE (-1)
+#define C4_RESULT_XWIN 0
+#define C4_RESULT_DRAW 1
+#define C4_RESULT_OWIN 2
+
+/* How leaf positions are evaluated (the `evaluator` argument of mcts.py:70-76 / :94-97). */
+#define C4_EVAL_EXTERNAL_F32 0 /* values float32[n], priors float32[n][7] written by the caller (the
+                                  net: model.py:269-282).  PUCT score arithmetic follows what the
+                                  reference does with a float32 prior under NumPy>=2 (float32). */
+#define C4_EVAL_EXTERNAL_F64 1 /* values float64[n], priors float64[n][7] (a Python evaluator
+                                  returning float64, e.g. a table or heuristic): float64 scoring. */
+#define C4_EVAL_CENTRE 2       /* evaluators.py:28-38 evaluate_centre_with_prior computed in-kernel;
+                                  whole searches run inside one launch (no leaf round trip). */
+
+#define C4_RNG_PHILOX 0 /* counter-based in-kernel RNG keyed by (seed, game id, ply) */
+#define C4_RNG_TAPE 1   /* caller-injected Gamma draws / uniforms (parity tests: the reference uses
+                           NumPy's global Mersenne state, mcts.py:175-177, tree.py:80) */
+
+#define C4_PLANES_F32 0
+#define C4_PLANES_F16 1
+#define C4_PLANES_BF16 2
+
+/* mcts.py:13-26 MCTSConfig + engine shape. */
+typedef struct {
+    int32_t abi_version;               /* = C4_ABI_VERSION */
+    int32_t n_slots;                   /* games advanced in lock-step on this GPU */
+    int32_t simulations;               /* mcts.py:15 */
+    int32_t pb_c_base;                 /* mcts.py:16 (19652) */
+    double  pb_c_init;                 /* mcts.py:17 (1.25) */
+    double  root_dirichlet_alpha;      /* mcts.py:18 */
+    double  root_exploration_fraction; /* mcts.py:19 */
+    int32_t num_sampling_moves;        /* mcts.py:20 */
+    int32_t eval_mode;                 /* C4_EVAL_* */
+    int32_t rng_mode;                  /* C4_RNG_* */
+    uint64_t seed;
+    int32_t stop_after_move;           /* 1: a slot parks after choosing ONE move (MCTS.make_move,
+                                          mcts.py:78-88); 0: continuous self-play (training_game.py:8-19) */
+    int64_t games_target;              /* self-play: slots park once this many games were started;
+                                          <0 = unbounded (bench) */
+    int32_t record_capacity_games;     /* ring of finished-game records kept on device */
+    int32_t max_inner_iters;           /* cap on simulations a slot may complete inside one launch
+                                          without needing the evaluator (terminal leaves); bounds
+                                          launch time.  0 = default */
+    int32_t planes_dtype;              /* C4_PLANES_* layout of the leaf batch handed to the net */
+    int32_t reserved[7];
+} c4_config;
+
+typedef struct c4_engine c4_engine;
+
+/* Aggregate counters since the last c4_reset (units defined in SURVEY.md section 8d). */
+typedef struct {
+    int64_t simulations;        /* iterations of mcts.py:107-120 completed */
+    int64_t expansions;         /* expand_node calls that materialise children (mcts.py:115) */
+    int64_t children_created;
+    int64_t terminal_sims;      /* simulations that ended on a terminal leaf (no evaluator call) */
+    int64_t leaf_evals;         /* leaves handed to the evaluator (incl. one root per move) */
+    int64_t depth_sum;          /* sum over simulations of leaf depth */
+    int64_t moves;              /* moves chosen (mcts.py:78-88) */
+    int64_t games_started;
+    int64_t games_finished;
+    int64_t launches;           /* rollout-step kernel launches */
+    int64_t active_slots;       /* slots not parked right now */
+    int64_t capped_slots;       /* slot-launches that hit max_inner_iters */
+} c4_stats;
+
+/* Root read-out of one slot (tree.py:66-117; what MCTS.make_move returns, mcts.py:88). */
+typedef struct {
+    int32_t  state;             /* 0 searching, 1 parked (no game), 2 move chosen */
+    int32_t  move;              /* chosen column or -1 */
+    double   value;             /* child.data.absolute_value of the chosen child (NaN if None) */
+    uint32_t root_visits;
+    double   root_value_sum;
+    uint32_t child_visits[7];
+    double   child_value_sum[7];
+    int32_t  child_status[7];   /* -2 absent, -1 non-terminal, else C4_RESULT_* */
+    double   root_prior[7];     /* normalised (+ noise) prior used at the root */
+    double   values_policy[7];  /* tree.py:104-109 */
+    uint64_t color0, color1;    /* root position searched */
+    int64_t  expansions;
+    int64_t  simulations;
+} c4_root_result;
+
+/* One finished self-play game (training_game.py:42-67 GameData). */
+typedef struct {
+    int64_t  game_id;
+    int32_t  length;
+    int32_t  result;            /* C4_RESULT_* */
+    uint64_t color0[42], color1[42];   /* board BEFORE each move (training_game.py:12) */
+    int32_t  move[42];
+    double   value[42];         /* child.data.absolute_value (training_game.py:13) */
+    double   policy[42][7];     /* tree.get_values_policy() (training_game.py:14) */
+} c4_game_record;
+
+/* -- lifecycle ------------------------------------------------------------------------------- */
+/* Replaces constructing MCTS(name, MCTSConfig, evaluator) (mcts.py:70-76) + the game_pool /
+ * InferenceServer scaffolding (game_pool.py:15-42, inference_server.py:15-63). */
+int c4_engine_create(const c4_config *cfg, int device, c4_engine **out);
+int c4_engine_destroy(c4_engine *e);
+const char *c4_last_error(const c4_engine *e /* may be NULL */);
+/* Order the engine's kernels with the caller's stream (torch.cuda.current_stream().cuda_stream). */
+int c4_set_stream(c4_engine *e, void *hip_stream);
+
+/* Start positions for the first n_active slots (Tree(board), tree.py:62-64); NULL => empty boards
+ * (Board(), board.py:36-41).  Remaining slots park.  Clears counters, records and game ids. */
+int c4_reset(c4_engine *e, const uint64_t *color0, const uint64_t *color1, int32_t n_active);
+
+/* C4_RNG_TAPE: gamma_noise[game][ply][7] raw Gamma(alpha,1) draws (mcts.py:175-177) and
+ * uniforms[game][ply] (the one uniform np.random.choice consumes, tree.py:80). `n_games` rows. */
+int c4_set_tapes(c4_engine *e, const double *gamma_noise, const double *uniforms, int32_t n_games);
+
+/* -- the hot path --------------------------------------------------------------------------- */
+/* One rollout step for every live slot, asynchronous on the engine's stream:
+ *   1. apply the evaluator's answer for the slot's pending leaf (mcts.py:124-135 evaluate_node:
+ *      mask + normalise prior, store; root: add_exploration_noise mcts.py:171-181), create the
+ *      children (tree.py:119-132) and back the value up the path (mcts.py:164-168);
+ *   2. run simulations (mcts.py:107-116: PUCT descent ucb_score/select_child mcts.py:138-161)
+ *      until the slot needs the evaluator again; terminal leaves are scored in place
+ *      (mcts.py:125-128); after `simulations` sims choose the move (mcts.py:81-86), record it
+ *      (training_game.py:12-15) and re-root;
+ *   3. write the slot's leaf as NN input planes (board.py:147-154 to_array) into planes_dev
+ *      [n_slots][3][6][7] and its bitboards into the engine's leaf buffers.
+ * values_dev / priors_dev hold the answers for the leaves emitted by the PREVIOUS step, in slot
+ * order (dtype per eval_mode; ignored by C4_EVAL_CENTRE; may be NULL on the first step).
+ * planes_dev may be NULL when the caller evaluates from the bitboards instead. */
+int c4_step(c4_engine *e, const void *values_dev, const void *priors_dev, void *planes_dev);
+
+/* C4_EVAL_CENTRE convenience: launch until every slot has parked (stop_after_move) or
+ * max_launches is reached.  Synchronous. */
+int c4_run_centre(c4_engine *e, int32_t max_launches);
+
+/* Leaves emitted by the last step: device views (engine-owned, valid until destroy) ... */
+int c4_leaf_buffers(c4_engine *e, const uint64_t **color0_dev, const uint64_t **color1_dev,
+                    const int32_t **has_leaf_dev);
+/* ... and a synchronous host copy (for Python evaluators, evaluators.py:18-25). */
+int c4_read_leaves(c4_engine *e, uint64_t *color0, uint64_t *color1, int32_t *has_leaf);
+
+/* -- read-out ------------------------------------------------------------------------------- */
+int c4_get_stats(c4_engine *e, c4_stats *out);                 /* synchronous */
+int c4_read_roots(c4_engine *e, c4_root_result *out /* [n_slots] */);   /* synchronous */
+/* Finished games not yet drained, in game-id order (training.py:131 games.extend). */
+int c4_drain_games(c4_engine *e, c4_game_record *out, int32_t cap, int32_t *n_out);
+
+/* -- pure board functions, executed by the device code (bit-exact parity tests) ------------- */
+/* board.py:160-170 make_move + result */
+int c4_board_make_move(int device, const uint64_t *color0, const uint64_t *color1, const int32_t *col,
+                       int32_t n, uint64_t *out0, uint64_t *out1, int32_t *result);
+/* board.py:173-184 _check_terminal_position */
+int c4_board_wins(int device, const uint64_t *stones, int32_t n, int32_t *out);
+/* board.py:88-92 valid_moves as a 7-bit mask (0 when the position is decided, board.py:56-62) */
+int c4_board_valid_mask(int device, const uint64_t *color0, const uint64_t *color1, int32_t n, int32_t *out);
+/* board.py:147-154 to_array, float32 [n][3][6][7] */
+int c4_board_planes(int device, const uint64_t *color0, const uint64_t *color1, int32_t n, float *out);
+/* board.py:115-145 create_fliplr / flip_color */
+int c4_board_fliplr(int device, const uint64_t *color0, const uint64_t *color1, int32_t n,
+                    uint64_t *out0, uint64_t *out1);
+/* evaluators.py:28-33 evaluate_centre (float64) */
+int c4_board_centre_value(int device, const uint64_t *color0, const uint64_t *color1, int32_t n, double *out);
+
+int c4_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1239 @@
+// c4_engine.hip -- MI355X (gfx950) self-play / MCTS engine behind the C ABI of include/c4_engine.h.
+//
+// Design (DESIGN.md has the long form):
+//   * thousands of games ("slots") advance in lock-step; each slot owns a private node pool in HBM
+//     laid out struct-of-arrays: N u32 | W f64 | P f64 | info u32, indexed slot*cap + node;
+//   * children of a node are created together in one 8-aligned block, in ascending column order, so
+//     the 7 lanes that score them read 7 consecutive elements of each array (one cache line each);
+//   * one slot = one 8-lane group of a wave64 (8 slots per wave): lane k scores child k, the PUCT
+//     argmax is a 3-step xor-shuffle butterfly over the group;
+//   * boards are never stored per node: the descent replays moves on a register bitboard;
+//   * children are materialised when their parent is EVALUATED (so the prior can live with the
+//     child); the reference's "expand on second visit" (mcts.py:114-115) is the moment a node with
+//     N==1 is first descended through -- that is what the expansion counter counts;
+//   * score arithmetic reproduces the reference bit-for-bit: float64 everywhere, or NumPy>=2's
+//     float32 path when the prior is a float32 net output (see ucb_score below); log() comes from a
+//     host-built table so device libm never enters the comparison.  Build with -ffp-contract=off.
+//
+// No CUDA-compat headers, no dual code paths, no CPU fallback: every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bfloat16.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "../../include/c4_engine.h"
+#include "c4_board.h"
+
+namespace {
+
+using namespace c4;
+
+constexpr int GROUP = 8;            // lanes per slot
+constexpr int SLOTS_PER_BLOCK = 8;  // one wave64 per block
+constexpr int BLOCK = GROUP * SLOTS_PER_BLOCK;
+constexpr int MAX_DEPTH = 44;       // root + 42 plies + 1
+
+// slot states
+constexpr int SLOT_ACTIVE = 0;
+constexpr int SLOT_PARKED = 1;
+constexpr int SLOT_MOVE_DONE = 2;
+
+// info word: [0:21] child_base (slots) | [22:24] nchild | [25:27] status | [28:30] move | [31] prior is f64
+__host__ __device__ __forceinline__ uint32_t pack_info(uint32_t base, uint32_t nchild, uint32_t status,
+                                                       uint32_t move, uint32_t pf64)
+{
+    return base | (nchild << 22) | (status << 25) | (move << 28) | (pf64 << 31);
+}
+__host__ __device__ __forceinline__ uint32_t info_base(uint32_t i) { return i & 0x3fffffu; }
+__host__ __device__ __forceinline__ uint32_t info_nchild(uint32_t i) { return (i >> 22) & 7u; }
+__host__ __device__ __forceinline__ uint32_t info_status(uint32_t i) { return (i >> 25) & 7u; }
+__host__ __device__ __forceinline__ uint32_t info_move(uint32_t i) { return (i >> 28) & 7u; }
+__host__ __device__ __forceinline__ uint32_t info_pf64(uint32_t i) { return i >> 31; }
+
+struct __attribute__((aligned(16))) PathEntry {
+    uint32_t node;
+    uint32_t n;   // visit count seen during the descent
+    double w;     // value sum seen during the descent
+};
+
+struct SlotStats {  // per-slot counters (summed on the host; no atomics => deterministic)
+    uint64_t sims, expansions, children, terminal_sims, leaf_evals, depth_sum, moves, games_started,
+        games_finished, capped;
+};
+constexpr int N_STATS = sizeof(SlotStats) / sizeof(uint64_t);
+
+struct Dev {
+    // node pools (SoA)
+    uint32_t *N;
+    double *W;
+    double *P;
+    uint32_t *info;
+    // slot state
+    uint64_t *root_c0, *root_c1, *leaf_c0, *leaf_c1;
+    int32_t *has_leaf;
+    int32_t *pending;        // node awaiting its evaluation, -1 none
+    uint32_t *pending_depth;
+    uint32_t *pending_info;
+    uint32_t *sims_done;
+    uint32_t *n_alloc;       // next free 8-slot block
+    int32_t *state;
+    int32_t *need_root;
+    uint32_t *ply;
+    long long *game_id;
+    PathEntry *path;         // [G][MAX_DEPTH]
+    uint64_t *stats;         // [G][N_STATS]
+    // per-slot result of the last chosen move
+    int32_t *res_move;
+    double *res_value;
+    double *res_policy;      // [G][7]
+    // score tables, index = parent visit count
+    const double *tabA;      // log((n + base + 1)/base) + init   (mcts.py:150-152)
+    const double *tabB;      // sqrt(n)                           (mcts.py:156)
+    // RNG tapes (C4_RNG_TAPE)
+    const double *noise_tape;  // [tape_games][42][7]
+    const double *u_tape;      // [tape_games][42]
+    int tape_games;
+    // finished-game records, ring over game id
+    uint64_t *rec_c0, *rec_c1;   // [rec_cap][42]
+    int32_t *rec_move;
+    double *rec_value;
+    double *rec_policy;          // [rec_cap][42][7]
+    int32_t *game_len;           // [rec_cap] 0 = not finished
+    int32_t *game_result;
+    long long *game_tag;         // [rec_cap] id stored in the ring slot
+    unsigned long long *next_game;
+    // config
+    int G;
+    uint32_t cap;
+    int S;
+    int nsm;
+    int use_noise;
+    int rng_tape;
+    int stop_after_move;
+    int max_inner;
+    int planes_dtype;
+    int rec_cap;
+    long long games_target;
+    double alpha, frac;
+    uint64_t seed;
+};
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double gshfl(double v, int src) { return __shfl(v, src, GROUP); }
+__device__ __forceinline__ float gshfl(float v, int src) { return __shfl(v, src, GROUP); }
+__device__ __forceinline__ int gshfl(int v, int src) { return __shfl(v, src, GROUP); }
+__device__ __forceinline__ uint32_t gshfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, GROUP); }
+
+// Orders this wave's global + LDS stores before its later loads (lanes of a group communicate
+// through memory inside one wave).  Workgroup scope = the same CU's L1, which is what we need.
+__device__ __forceinline__ void group_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Philox4x32-10 (counter-based; Salmon et al. 2011)
+__device__ __forceinline__ void philox_round(uint32_t c[4], const uint32_t k[2])
+{
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ inline void philox4x32(uint32_t c[4], uint64_t seed)
+{
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k);
+        k[0] += 0x9E3779B9u;
+        k[1] += 0xBB67AE85u;
+    }
+}
+// two uniforms in [0,1) from one Philox block
+__device__ inline void rng_uniform2(uint64_t seed, long long gid, uint32_t ply, uint32_t stream, uint32_t idx,
+                                    double &u0, double &u1)
+{
+    uint32_t c[4] = {(uint32_t)gid, (uint32_t)((uint64_t)gid >> 32), ply * 64u + stream, idx};
+    philox4x32(c, seed);
+    u0 = (double)((((uint64_t)c[0] << 32) | c[1]) >> 11) * (1.0 / 9007199254740992.0);
+    u1 = (double)((((uint64_t)c[2] << 32) | c[3]) >> 11) * (1.0 / 9007199254740992.0);
+}
+// Gamma(alpha,1), Marsaglia-Tsang with the alpha<1 boost; bounded rejection loop.
+__device__ inline double rng_gamma(uint64_t seed, long long gid, uint32_t ply, uint32_t stream, double alpha)
+{
+    double u0, u1;
+    rng_uniform2(seed, gid, ply, stream, 0, u0, u1);
+    double boost = 1.0;
+    if (alpha < 1.0) {
+        boost = pow(u0 > 0.0 ? u0 : 1e-300, 1.0 / alpha);
+        alpha += 1.0;
+    }
+    const double dd = alpha - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * dd);
+    for (uint32_t it = 1; it <= 24; ++it) {
+        double a, b, uu, unused;
+        rng_uniform2(seed, gid, ply, stream, 2 * it, a, b);
+        rng_uniform2(seed, gid, ply, stream, 2 * it + 1, uu, unused);
+        const double x = sqrt(-2.0 * log(a > 0.0 ? a : 1e-300)) * cos(6.283185307179586 * b);
+        double v = 1.0 + cc * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        if (uu < 1.0 - 0.0331 * x * x * x * x) return boost * dd * v;
+        if (log(uu > 0.0 ? uu : 1e-300) < 0.5 * x * x + dd * (1.0 - v + log(v))) return boost * dd * v;
+    }
+    return boost * dd;
+}
+
+// tree.py:27-44 + utils.py:33-34: value of a child from `side`'s point of view.
+__device__ __forceinline__ double child_value_for(uint32_t status, uint32_t n, double w, int side)
+{
+    double v;
+    if (status >= ST_XWIN) v = 0.5 * (double)(status - ST_XWIN);  // exact result, not the running mean
+    else if (n > 0) v = w / (double)n;
+    else return 0.0;                                               // unknown: assume lost
+    return side == 0 ? v : 1.0 - v;
+}
+
+// mcts.py:147-161 ucb_score.  A = log(..)+pb_c_init and B = sqrt(Np) come from the host tables.
+// pf64: the parent's prior is float64 (heuristic / table evaluator, or the root after Dirichlet
+// noise, mcts.py:180).  Otherwise it is a float32 net output and NumPy>=2 keeps
+// `pb_c * prior[c]` and `prior_score + value_score` in float32 (weak Python scalars, NEP 50).
+__device__ __forceinline__ double ucb_score(double A, double B, uint32_t nc, double p, double V, uint32_t pf64)
+{
+    const double pbc = A * (B / (double)(nc + 1));
+    if (pf64) {
+        const double prior_score = pbc * p;
+        return prior_score + V;
+    }
+    const float prior_score = (float)pbc * (float)p;
+    const float s = prior_score + (float)V;
+    return (double)s;
+}
+
+// argmax over the group on (score, k); ties -> larger k == higher column (tree.py:11-15).
+__device__ __forceinline__ int group_argmax(double s, int k)
+{
+#pragma unroll
+    for (int m = 1; m < GROUP; m <<= 1) {
+        const double os = __shfl_xor(s, m, GROUP);
+        const int ok = __shfl_xor(k, m, GROUP);
+        if (os > s || (os == s && ok > k)) { s = os; k = ok; }
+    }
+    return k;
+}
+
+template <typename T>
+__device__ __forceinline__ void store_plane(void *planes, size_t idx, float v);
+template <> __device__ __forceinline__ void store_plane<float>(void *p, size_t i, float v) { ((float *)p)[i] = v; }
+template <> __device__ __forceinline__ void store_plane<__half>(void *p, size_t i, float v) { ((__half *)p)[i] = __float2half(v); }
+template <> __device__ __forceinline__ void store_plane<hip_bfloat16>(void *p, size_t i, float v) { ((hip_bfloat16 *)p)[i] = hip_bfloat16(v); }
+
+// ------------------------------------------------------------------------------------------
+// the rollout-step kernel
+// ------------------------------------------------------------------------------------------
+template <int EVAL>
+__global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__restrict__ values_in,
+                                                        const void *__restrict__ priors_in,
+                                                        void *__restrict__ planes_out)
+{
+    __shared__ PathEntry s_path[SLOTS_PER_BLOCK][MAX_DEPTH];
+
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int gl = threadIdx.x / GROUP;
+    const int g = blockIdx.x * SLOTS_PER_BLOCK + gl;
+    if (g >= d.G) return;
+    if (d.state[g] != SLOT_ACTIVE) {
+        if (lane == 0) d.has_leaf[g] = 0;
+        return;
+    }
+    constexpr bool SCORE_F32 = (EVAL == C4_EVAL_EXTERNAL_F32);
+
+    const size_t nb = (size_t)g * d.cap;
+    uint32_t *__restrict__ aN = d.N + nb;
+    double *__restrict__ aW = d.W + nb;
+    double *__restrict__ aP = d.P + nb;
+    uint32_t *__restrict__ aI = d.info + nb;
+    PathEntry *gpath = d.path + (size_t)g * MAX_DEPTH;
+
+    // slot state (group-uniform registers)
+    uint64_t root0 = d.root_c0[g], root1 = d.root_c1[g];
+    uint32_t sims = d.sims_done[g];
+    uint32_t nalloc = d.n_alloc[g];
+    int32_t pend = d.pending[g];
+    uint32_t pdepth = d.pending_depth[g];
+    uint32_t pinfo = d.pending_info[g];
+    int32_t need_root = d.need_root[g];
+    uint32_t ply = d.ply[g];
+    long long gid = d.game_id[g];
+    int state = SLOT_ACTIVE;
+    int has_leaf = 0;
+    SlotStats st = {};
+
+    // evaluator answer for the pending leaf
+    uint64_t leaf0 = 0, leaf1 = 0;
+    double ev_value = 0.0, ev_prior = 0.0;   // ev_prior: lane k holds prior[k]
+    bool apply_now = false;
+    if (pend >= 0) {
+        leaf0 = d.leaf_c0[g];
+        leaf1 = d.leaf_c1[g];
+        if (EVAL == C4_EVAL_EXTERNAL_F32) {
+            ev_value = (double)((const float *)values_in)[g];
+            ev_prior = lane < 7 ? (double)((const float *)priors_in)[(size_t)g * 7 + lane] : 0.0;
+        } else if (EVAL == C4_EVAL_EXTERNAL_F64) {
+            ev_value = ((const double *)values_in)[g];
+            ev_prior = lane < 7 ? ((const double *)priors_in)[(size_t)g * 7 + lane] : 0.0;
+        }
+        apply_now = true;   // (C4_EVAL_CENTRE never leaves a leaf pending across launches)
+    }
+
+    int inner = 0;
+    for (;;) {
+        // ---------------------------------------------------------------- evaluate_node + expand + backup
+        if (apply_now) {
+            apply_now = false;
+            const uint64_t occ = leaf0 | leaf1;
+            const int age = popc64(occ);
+            const int mask = legal_mask(occ);                    // tree.py:23 valid_moves (leaf is undecided)
+            const bool legal = lane < 7 && ((mask >> lane) & 1);
+            // mcts.py:197-202 normalise, in the prior's own dtype
+            double prn;
+            uint32_t pf64;
+            if (SCORE_F32) {
+                const float pf = legal ? (float)ev_prior : 0.0f;
+                float s = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) s = s + gshfl(pf, i);
+                prn = (double)(pf / s);
+                pf64 = 0;
+            } else {
+                const double pd = legal ? ev_prior : 0.0;
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) s = s + gshfl(pd, i);
+                prn = pd / s;
+                pf64 = 1;
+            }
+            // mcts.py:171-181 add_exploration_noise (root only)
+            if (pdepth == 0 && d.use_noise) {
+                double nz = 0.0;
+                if (lane < 7) {
+                    if (d.rng_tape) nz = (gid < d.tape_games) ? d.noise_tape[((size_t)gid * 42 + ply) * 7 + lane] : 0.0;
+                    else nz = rng_gamma(d.seed, gid, ply, (uint32_t)lane, d.alpha);
+                }
+                if (!legal) nz = 0.0;
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) s = s + gshfl(nz, i);
+                nz = nz / s;
+                const double keep = 1.0 - d.frac;
+                const double a = SCORE_F32 ? (double)((float)prn * (float)keep) : prn * keep;
+                const double b = nz * d.frac;
+                prn = a + b;
+                pf64 = 1;
+            }
+            // tree.py:119-132: children in ascending column order, one 8-aligned block
+            const uint32_t nchild = (uint32_t)__popc(mask);
+            const uint32_t base = nalloc * GROUP;
+            nalloc += 1;
+            if (legal) {
+                const uint32_t k = (uint32_t)__popc(mask & ((1 << lane) - 1));
+                uint64_t c0 = leaf0, c1 = leaf1;
+                const uint32_t cst = make_move(c0, c1, lane);
+                const uint32_t idx = base + k;
+                aN[idx] = 0;
+                aW[idx] = 0.0;
+                aP[idx] = prn;
+                aI[idx] = pack_info(0, 0, cst, (uint32_t)lane, 0);
+            }
+            if (lane == 0) {   // mcts.py:132-134: position_value / search_value.add(value)
+                aN[pend] = 1;
+                aW[pend] = ev_value;
+                aI[pend] = pack_info(base, nchild, ST_EVALUATED, info_move(pinfo), pf64);
+            }
+            // mcts.py:164-168 backpropagate over the ancestors (values captured during the descent)
+            for (uint32_t i = lane; i < pdepth; i += GROUP) {
+                const PathEntry e = (EVAL == C4_EVAL_CENTRE) ? s_path[gl][i] : gpath[i];
+                aN[e.node] = e.n + 1;
+                aW[e.node] = e.w + ev_value;
+            }
+            st.leaf_evals += 1;
+            st.children += nchild;
+            if (pdepth > 0) sims += 1;
+            (void)age;
+            pend = -1;
+            group_fence();
+        }
+
+        // ---------------------------------------------------------------- new root (Tree(board), tree.py:62-64)
+        if (need_root) {
+            need_root = 0;
+            nalloc = 1;
+            sims = 0;
+            pend = 0;
+            pdepth = 0;
+            pinfo = pack_info(0, 0, ST_FRESH, 0, 0);
+            leaf0 = root0;
+            leaf1 = root1;
+            if (EVAL == C4_EVAL_CENTRE) {
+                ev_value = centre_value(leaf0, leaf1);
+                ev_prior = 1.0 / 7.0;
+                apply_now = true;
+                continue;
+            }
+            has_leaf = 1;
+            break;
+        }
+
+        // ---------------------------------------------------------------- move choice (mcts.py:78-88)
+        if (sims >= (uint32_t)d.S) {
+            const uint32_t rinfo = aI[0];
+            const uint32_t cb = info_base(rinfo), nc = info_nchild(rinfo);
+            const bool act = lane < (int)nc;
+            const uint32_t cn = act ? aN[cb + lane] : 0;
+            const double cw = act ? aW[cb + lane] : 0.0;
+            const uint32_t ci = act ? aI[cb + lane] : 0;
+            const int root_age = popc64(root0 | root1);
+            const int side = root_age & 1;
+            const double V = act ? child_value_for(info_status(ci), cn, cw, side) : 0.0;
+            // tree.py:104-109 + :139-147 values policy
+            double vs = 0.0;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) vs = vs + gshfl(V, i);
+            const double pol = act ? (vs == 0.0 ? 1.0 / (double)nc : V / vs) : 0.0;
+            // choose
+            int kb = -1;
+            double u = -1.0;
+            if (root_age < d.nsm) {
+                if (d.rng_tape) u = (gid < d.tape_games) ? d.u_tape[(size_t)gid * 42 + ply] : -1.0;
+                else { double u1; rng_uniform2(d.seed, gid, ply, 32u, 0, u, u1); }
+            }
+            if (u >= 0.0) {   // tree.py:75-82 sample_value_fn(x**2) via np.random.choice's inverse-CDF
+                const double w2 = V * V;
+                double s2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) s2 = s2 + gshfl(w2, i);
+                if (s2 > 0.0) {
+                    const double pk = w2 / s2;
+                    double acc = 0.0, cdf = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) {
+                        acc = acc + gshfl(pk, i);
+                        if (i == lane) cdf = acc;
+                    }
+                    const double last = gshfl(cdf, (int)nc - 1);
+                    cdf = cdf / last;
+                    const unsigned long long bal = __ballot(act && cdf <= u);
+                    int cnt = __popcll((bal >> (gl * GROUP)) & 0xffull);
+                    kb = cnt < (int)nc ? cnt : (int)nc - 1;
+                }
+            }
+            if (kb < 0) kb = group_argmax(act ? V : -1.0, act ? lane : -1);   // tree.py:69-73 best_move
+            const uint32_t bi = gshfl(ci, kb);
+            const uint32_t bn = gshfl(cn, kb);
+            const double bw = gshfl(cw, kb);
+            const int mv = (int)info_move(bi);
+            const uint32_t bst = info_status(bi);
+            double absv;   // child.data.absolute_value (mcts.py:88)
+            if (bst >= ST_XWIN) absv = 0.5 * (double)(bst - ST_XWIN);
+            else if (bn > 0) absv = bw / (double)bn;
+            else absv = __longlong_as_double(0x7ff8000000000000LL);
+            // policy by column
+            const int rmask = legal_mask(root0 | root1);
+            double pol_col = 0.0;
+            {
+                const int kk = __popc(rmask & ((1 << lane) - 1));
+                const double pv = gshfl(pol, kk & 7);
+                if (lane < 7 && ((rmask >> lane) & 1)) pol_col = pv;
+            }
+            // training_game.py:12-15 record (board before the move)
+            if (d.rec_cap > 0 && !d.stop_after_move) {
+                const size_t r = ((size_t)(gid % d.rec_cap)) * 42 + ply;
+                if (lane == 0) {
+                    d.rec_c0[r] = root0;
+                    d.rec_c1[r] = root1;
+                    d.rec_move[r] = mv;
+                    d.rec_value[r] = absv;
+                }
+                if (lane < 7) d.rec_policy[r * 7 + lane] = pol_col;
+            }
+            if (lane == 0) { d.res_move[g] = mv; d.res_value[g] = absv; }
+            if (lane < 7) d.res_policy[(size_t)g * 7 + lane] = pol_col;
+            st.moves += 1;
+            if (d.stop_after_move) {   // MCTS.make_move returns here; the tree stays readable
+                state = SLOT_MOVE_DONE;
+                break;
+            }
+            make_move(root0, root1, mv);   // board.make_move(child.name)
+            ply += 1;
+            if (bst >= ST_XWIN) {          // game over: training_game.py:17 game_data.result
+                if (d.rec_cap > 0 && lane == 0) {
+                    const size_t r = (size_t)(gid % d.rec_cap);
+                    d.game_result[r] = (int32_t)(bst - ST_XWIN);
+                    d.game_tag[r] = gid;
+                    __threadfence();
+                    d.game_len[r] = (int32_t)ply;
+                }
+                st.games_finished += 1;
+                unsigned long long ng = 0;
+                if (lane == 0) ng = atomicAdd(d.next_game, 1ULL);
+                ng = ((unsigned long long)gshfl((uint32_t)(ng >> 32), 0) << 32) | gshfl((uint32_t)ng, 0);
+                if (d.games_target >= 0 && (long long)ng >= d.games_target) {
+                    state = SLOT_PARKED;
+                    break;
+                }
+                gid = (long long)ng;
+                ply = 0;
+                root0 = 0;
+                root1 = 0;
+                st.games_started += 1;
+                if (d.rec_cap > 0 && lane == 0) d.game_len[(size_t)(gid % d.rec_cap)] = 0;
+            }
+            need_root = 1;
+            continue;
+        }
+
+        // bound the launch: at most max_inner evaluator-free simulations per launch
+        if (inner >= d.max_inner) {
+            st.capped += 1;
+            break;
+        }
+        inner += 1;
+
+        // ---------------------------------------------------------------- descent (mcts.py:108-116)
+        uint32_t cur = 0;
+        uint32_t cinfo = aI[0];
+        uint32_t cN = aN[0];
+        double cW = aW[0];
+        uint64_t b0 = root0, b1 = root1;
+        int age = popc64(b0 | b1);
+        uint32_t depth = 0;
+        if (lane == 0) s_path[gl][0] = PathEntry{0u, cN, cW};
+        while (info_status(cinfo) == ST_EVALUATED) {
+            const uint32_t cb = info_base(cinfo), nc = info_nchild(cinfo), pf64 = info_pf64(cinfo);
+            if (cN == 1) st.expansions += 1;   // first descent through an evaluated node == expand_node
+            const bool act = lane < (int)nc;
+            const uint32_t idx = cb + lane;
+            const uint32_t n = act ? aN[idx] : 0;
+            const double w = act ? aW[idx] : 0.0;
+            const double p = act ? aP[idx] : 0.0;
+            const uint32_t inf = act ? aI[idx] : 0;
+            const double A = d.tabA[cN], B = d.tabB[cN];
+            const double V = child_value_for(info_status(inf), n, w, age & 1);
+            const double s = act ? ucb_score(A, B, n, p, V, pf64) : -std::numeric_limits<double>::infinity();
+            const int kb = group_argmax(s, act ? lane : -1);   // mcts.py:141-142
+            const uint32_t binf = gshfl(inf, kb);
+            cN = gshfl(n, kb);
+            cW = gshfl(w, kb);
+            cinfo = binf;
+            cur = cb + (uint32_t)kb;
+            make_move(b0, b1, (int)info_move(binf));
+            age += 1;
+            depth += 1;
+            if (lane == 0) s_path[gl][depth] = PathEntry{cur, cN, cW};
+        }
+        st.depth_sum += depth;
+        const uint32_t lst = info_status(cinfo);
+        if (lst >= ST_XWIN) {
+            // mcts.py:125-128,134 + :164-168: terminal leaf, exact result, no evaluator
+            const double value = 0.5 * (double)(lst - ST_XWIN);
+            group_fence();   // s_path written by lane 0
+            for (uint32_t i = lane; i <= depth; i += GROUP) {
+                const PathEntry e = s_path[gl][i];
+                aN[e.node] = e.n + 1;
+                aW[e.node] = e.w + value;
+            }
+            sims += 1;
+            st.sims += 1;
+            st.terminal_sims += 1;
+            group_fence();
+            continue;
+        }
+        // fresh non-terminal leaf: needs the evaluator (mcts.py:130)
+        pend = (int32_t)cur;
+        pdepth = depth;
+        pinfo = cinfo;
+        leaf0 = b0;
+        leaf1 = b1;
+        st.sims += 1;   // counted when issued; completes in the next launch's apply
+        if (EVAL == C4_EVAL_CENTRE) {
+            ev_value = centre_value(b0, b1);
+            ev_prior = 1.0 / 7.0;
+            group_fence();   // s_path -> read by the apply above
+            apply_now = true;
+            continue;
+        }
+        group_fence();
+        for (uint32_t i = lane; i < depth; i += GROUP) gpath[i] = s_path[gl][i];
+        has_leaf = 1;
+        break;
+    }
+
+    // ---------------------------------------------------------------- emit leaf + persist slot state
+    if (has_leaf) {
+        if (lane == 0) { d.leaf_c0[g] = leaf0; d.leaf_c1[g] = leaf1; }
+        if (planes_out) {
+            const int o_to_move = (popc64(leaf0 | leaf1) & 1) ? 0 : 1;
+            const size_t pb = (size_t)g * 126;
+            for (int e = lane; e < 126; e += GROUP) {
+                const float v = plane_element(leaf0, leaf1, o_to_move, e);
+                if (d.planes_dtype == C4_PLANES_F32) store_plane<float>(planes_out, pb + e, v);
+                else if (d.planes_dtype == C4_PLANES_F16) store_plane<__half>(planes_out, pb + e, v);
+                else store_plane<hip_bfloat16>(planes_out, pb + e, v);
+            }
+        }
+    }
+    if (lane == 0) {
+        d.has_leaf[g] = has_leaf;
+        d.root_c0[g] = root0;
+        d.root_c1[g] = root1;
+        d.sims_done[g] = sims;
+        d.n_alloc[g] = nalloc;
+        d.pending[g] = has_leaf ? pend : -1;
+        d.pending_depth[g] = pdepth;
+        d.pending_info[g] = pinfo;
+        d.need_root[g] = need_root;
+        d.ply[g] = ply;
+        d.game_id[g] = gid;
+        d.state[g] = state;
+        uint64_t *sp = d.stats + (size_t)g * N_STATS;
+        const uint64_t *sv = (const uint64_t *)&st;
+#pragma unroll
+        for (int i = 0; i < N_STATS; ++i) sp[i] += sv[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------
+__global__ void c4_reset_kernel(Dev d, const uint64_t *c0, const uint64_t *c1, int n_active)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.G) return;
+    const bool active = g < n_active;
+    d.root_c0[g] = (active && c0) ? c0[g] : 0;
+    d.root_c1[g] = (active && c1) ? c1[g] : 0;
+    d.leaf_c0[g] = 0;
+    d.leaf_c1[g] = 0;
+    d.has_leaf[g] = 0;
+    d.pending[g] = -1;
+    d.pending_depth[g] = 0;
+    d.pending_info[g] = 0;
+    d.sims_done[g] = 0;
+    d.n_alloc[g] = 1;
+    d.state[g] = active ? SLOT_ACTIVE : SLOT_PARKED;
+    d.need_root[g] = active ? 1 : 0;
+    d.ply[g] = 0;
+    d.game_id[g] = g;
+    d.res_move[g] = -1;
+    d.res_value[g] = 0.0;
+    for (int i = 0; i < 7; ++i) d.res_policy[(size_t)g * 7 + i] = 0.0;
+    uint64_t *sp = d.stats + (size_t)g * N_STATS;
+    for (int i = 0; i < N_STATS; ++i) sp[i] = 0;
+    if (active) sp[offsetof(SlotStats, games_started) / 8] = 1;
+    if (g == 0) *d.next_game = (unsigned long long)n_active;
+    for (int r = g; r < d.rec_cap; r += d.G) { d.game_len[r] = 0; d.game_result[r] = -1; d.game_tag[r] = -1; }
+}
+
+__global__ void c4_gather_roots_kernel(Dev d, c4_root_result *out)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.G) return;
+    c4_root_result r;
+    memset(&r, 0, sizeof(r));
+    const size_t nb = (size_t)g * d.cap;
+    r.state = d.state[g];
+    r.move = d.res_move[g];
+    r.value = d.res_value[g];
+    r.color0 = d.root_c0[g];
+    r.color1 = d.root_c1[g];
+    const uint32_t rinfo = d.info[nb];
+    for (int i = 0; i < 7; ++i) { r.child_status[i] = -2; r.values_policy[i] = d.res_policy[(size_t)g * 7 + i]; }
+    if (info_status(rinfo) == ST_EVALUATED) {
+        r.root_visits = d.N[nb];
+        r.root_value_sum = d.W[nb];
+        const uint32_t cb = info_base(rinfo), nc = info_nchild(rinfo);
+        for (uint32_t k = 0; k < nc; ++k) {
+            const uint32_t ci = d.info[nb + cb + k];
+            const int m = (int)info_move(ci);
+            r.child_visits[m] = d.N[nb + cb + k];
+            r.child_value_sum[m] = d.W[nb + cb + k];
+            r.child_status[m] = info_status(ci) >= ST_XWIN ? (int32_t)(info_status(ci) - ST_XWIN) : -1;
+            r.root_prior[m] = d.P[nb + cb + k];
+        }
+    }
+    const uint64_t *sp = d.stats + (size_t)g * N_STATS;
+    r.expansions = (int64_t)sp[offsetof(SlotStats, expansions) / 8];
+    r.simulations = (int64_t)sp[offsetof(SlotStats, sims) / 8];
+    out[g] = r;
+}
+
+__global__ void k_make_move(const uint64_t *c0, const uint64_t *c1, const int32_t *col, int n, uint64_t *o0,
+                            uint64_t *o1, int32_t *res)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t a = c0[i], b = c1[i];
+    const uint32_t st = make_move(a, b, col[i]);
+    o0[i] = a;
+    o1[i] = b;
+    res[i] = st >= ST_XWIN ? (int32_t)(st - ST_XWIN) : C4_RESULT_NONE;
+}
+__global__ void k_wins(const uint64_t *s, int n, int32_t *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = wins(s[i]) ? 1 : 0;
+}
+__global__ void k_valid_mask(const uint64_t *c0, const uint64_t *c1, int n, int32_t *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = position_status(c0[i], c1[i]) == ST_FRESH ? legal_mask(c0[i] | c1[i]) : 0;
+}
+__global__ void k_planes(const uint64_t *c0, const uint64_t *c1, int n, float *out)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * 126) return;
+    const size_t i = t / 126;
+    const int e = (int)(t - i * 126);
+    const int o_to_move = (popc64(c0[i] | c1[i]) & 1) ? 0 : 1;
+    out[t] = plane_element(c0[i], c1[i], o_to_move, e);
+}
+__global__ void k_fliplr(const uint64_t *c0, const uint64_t *c1, int n, uint64_t *o0, uint64_t *o1)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    o0[i] = flip_color(c0[i]);
+    o1[i] = flip_color(c1[i]);
+}
+__global__ void k_centre(const uint64_t *c0, const uint64_t *c1, int n, double *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = centre_value(c0[i], c1[i]);
+}
+
+thread_local char g_err[512] = "";
+
+void set_err(char *dst, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    if (dst != g_err) { strncpy(g_err, dst, 511); g_err[511] = 0; }
+}
+
+}  // namespace
+
+struct c4_engine {
+    c4_config cfg;
+    int device;
+    hipStream_t stream;
+    Dev d;
+    std::vector<void *> allocs;
+    std::vector<long long> drained_tag;   // per ring slot: game id already handed out (-1 none)
+    int64_t launches;
+    int tape_games;
+    double *tape_noise, *tape_u;
+    char err[512];
+};
+
+#define HIPCHK(e, call)                                                                        \
+    do {                                                                                       \
+        hipError_t _r = (call);                                                                \
+        if (_r != hipSuccess) {                                                                \
+            set_err((e) ? (e)->err : g_err, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_r), \
+                    __FILE__, __LINE__);                                                       \
+            return C4_EDEVICE;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+namespace {
+
+template <typename T>
+int dev_alloc(c4_engine *e, T **p, size_t count)
+{
+    void *q = nullptr;
+    hipError_t r = hipMalloc(&q, count * sizeof(T) ? count * sizeof(T) : 16);
+    if (r != hipSuccess) {
+        set_err(e->err, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(r));
+        return C4_ENOMEM;
+    }
+    e->allocs.push_back(q);
+    *p = (T *)q;
+    return C4_OK;
+}
+
+int check_device(int device, char *err)
+{
+    int n = 0;
+    hipError_t r = hipGetDeviceCount(&n);
+    if (r != hipSuccess || n <= 0) {
+        set_err(err, "no HIP device available (%s): the engine has no CPU fallback",
+                r == hipSuccess ? "device count 0" : hipGetErrorString(r));
+        return C4_EDEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_err(err, "device %d out of range (have %d); there is no CPU backend", device, n);
+        return C4_EDEVICE;
+    }
+    r = hipSetDevice(device);
+    if (r != hipSuccess) {
+        set_err(err, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(r));
+        return C4_EDEVICE;
+    }
+    return C4_OK;
+}
+
+// scratch helper for the pure board entry points
+struct Scratch {
+    std::vector<void *> ptrs;
+    ~Scratch() { for (void *p : ptrs) (void)hipFree(p); }
+    template <typename T>
+    T *up(const T *host, size_t n, hipError_t &r)
+    {
+        void *q = nullptr;
+        if (r != hipSuccess) return nullptr;
+        r = hipMalloc(&q, n * sizeof(T) ? n * sizeof(T) : 16);
+        if (r != hipSuccess) return nullptr;
+        ptrs.push_back(q);
+        if (host) r = hipMemcpy(q, host, n * sizeof(T), hipMemcpyHostToDevice);
+        return (T *)q;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int c4_abi_version(void) { return C4_ABI_VERSION; }
+
+const char *c4_last_error(const c4_engine *e) { return e ? e->err : g_err; }
+
+int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
+{
+    if (!cfg || !out) { set_err(g_err, "c4_engine_create: null argument"); return C4_EINVAL; }
+    *out = nullptr;
+    if (cfg->abi_version != C4_ABI_VERSION) { set_err(g_err, "ABI version mismatch: caller %d, library %d", cfg->abi_version, C4_ABI_VERSION); return C4_EINVAL; }
+    if (cfg->n_slots <= 0 || cfg->simulations <= 0 || cfg->pb_c_base <= 0) { set_err(g_err, "n_slots, simulations and pb_c_base must be positive"); return C4_EINVAL; }
+    if (cfg->eval_mode < 0 || cfg->eval_mode > 2 || cfg->rng_mode < 0 || cfg->rng_mode > 1 || cfg->planes_dtype < 0 || cfg->planes_dtype > 2) { set_err(g_err, "bad eval_mode / rng_mode / planes_dtype"); return C4_EINVAL; }
+    // every evaluated node takes one 8-slot block; evaluations per move <= simulations + 1
+    const uint64_t cap = (uint64_t)GROUP * ((uint64_t)cfg->simulations + 3);
+    if (cap > (1u << 22)) { set_err(g_err, "simulations=%d exceeds the 22-bit node index (max %d)", cfg->simulations, (1 << 19) - 3); return C4_ECAPACITY; }
+    int rc = check_device(device, g_err);
+    if (rc) return rc;
+
+    c4_engine *e = new c4_engine();
+    e->cfg = *cfg;
+    e->device = device;
+    e->stream = nullptr;
+    e->launches = 0;
+    e->tape_games = 0;
+    e->tape_noise = nullptr;
+    e->tape_u = nullptr;
+    e->err[0] = 0;
+    memset(&e->d, 0, sizeof(Dev));
+    Dev &d = e->d;
+    const size_t G = (size_t)cfg->n_slots;
+    d.G = cfg->n_slots;
+    d.cap = (uint32_t)cap;
+    d.S = cfg->simulations;
+    d.nsm = cfg->num_sampling_moves;
+    d.alpha = cfg->root_dirichlet_alpha;
+    d.frac = cfg->root_exploration_fraction;
+    d.use_noise = (cfg->root_dirichlet_alpha != 0.0 && cfg->root_exploration_fraction != 0.0) ? 1 : 0;  // mcts.py:174
+    d.rng_tape = cfg->rng_mode == C4_RNG_TAPE;
+    d.stop_after_move = cfg->stop_after_move ? 1 : 0;
+    d.max_inner = cfg->max_inner_iters > 0 ? cfg->max_inner_iters
+                                            : (cfg->eval_mode == C4_EVAL_CENTRE ? 1 << 20 : 8);
+    d.planes_dtype = cfg->planes_dtype;
+    d.games_target = cfg->games_target;
+    d.seed = cfg->seed;
+    d.rec_cap = cfg->stop_after_move ? 0 : (cfg->record_capacity_games > 0 ? cfg->record_capacity_games : 2 * cfg->n_slots);
+
+#define ALLOC(ptr, count)                                   \
+    if ((rc = dev_alloc(e, &(ptr), (count))) != C4_OK) {    \
+        strncpy(g_err, e->err, 511);                        \
+        c4_engine_destroy(e);                               \
+        return rc;                                          \
+    }
+    ALLOC(d.N, G * cap);
+    ALLOC(d.W, G * cap);
+    ALLOC(d.P, G * cap);
+    ALLOC(d.info, G * cap);
+    ALLOC(d.root_c0, G); ALLOC(d.root_c1, G); ALLOC(d.leaf_c0, G); ALLOC(d.leaf_c1, G);
+    ALLOC(d.has_leaf, G); ALLOC(d.pending, G); ALLOC(d.pending_depth, G); ALLOC(d.pending_info, G);
+    ALLOC(d.sims_done, G); ALLOC(d.n_alloc, G); ALLOC(d.state, G); ALLOC(d.need_root, G);
+    ALLOC(d.ply, G); ALLOC(d.game_id, G);
+    ALLOC(d.path, G * MAX_DEPTH);
+    ALLOC(d.stats, G * N_STATS);
+    ALLOC(d.res_move, G); ALLOC(d.res_value, G); ALLOC(d.res_policy, G * 7);
+    ALLOC(d.next_game, 1);
+    const size_t R = (size_t)d.rec_cap;
+    ALLOC(d.rec_c0, R * 42); ALLOC(d.rec_c1, R * 42); ALLOC(d.rec_move, R * 42);
+    ALLOC(d.rec_value, R * 42); ALLOC(d.rec_policy, R * 42 * 7);
+    ALLOC(d.game_len, R); ALLOC(d.game_result, R); ALLOC(d.game_tag, R);
+    // score tables (host libm so that log() is the very function Python's math.log calls)
+    {
+        const size_t nt = (size_t)cfg->simulations + 4;
+        std::vector<double> A(nt), B(nt);
+        for (size_t n = 0; n < nt; ++n) {
+            A[n] = std::log((double)((long long)n + cfg->pb_c_base + 1) / (double)cfg->pb_c_base) + cfg->pb_c_init;
+            B[n] = std::sqrt((double)n);
+        }
+        double *tA, *tB;
+        ALLOC(tA, nt); ALLOC(tB, nt);
+        hipError_t r1 = hipMemcpy(tA, A.data(), nt * sizeof(double), hipMemcpyHostToDevice);
+        hipError_t r2 = hipMemcpy(tB, B.data(), nt * sizeof(double), hipMemcpyHostToDevice);
+        if (r1 != hipSuccess || r2 != hipSuccess) { set_err(g_err, "table upload failed"); c4_engine_destroy(e); return C4_EDEVICE; }
+        d.tabA = tA;
+        d.tabB = tB;
+    }
+#undef ALLOC
+    e->drained_tag.assign(R, -1);
+    *out = e;
+    rc = c4_reset(e, nullptr, nullptr, cfg->n_slots);
+    if (rc) { strncpy(g_err, e->err, 511); c4_engine_destroy(e); *out = nullptr; return rc; }
+    return C4_OK;
+}
+
+int c4_engine_destroy(c4_engine *e)
+{
+    if (!e) return C4_OK;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    for (void *p : e->allocs) (void)hipFree(p);
+    if (e->tape_noise) (void)hipFree(e->tape_noise);
+    if (e->tape_u) (void)hipFree(e->tape_u);
+    delete e;
+    return C4_OK;
+}
+
+int c4_set_stream(c4_engine *e, void *hip_stream)
+{
+    if (!e) return C4_EINVAL;
+    e->stream = (hipStream_t)hip_stream;
+    return C4_OK;
+}
+
+int c4_reset(c4_engine *e, const uint64_t *color0, const uint64_t *color1, int32_t n_active)
+{
+    if (!e) return C4_EINVAL;
+    if (n_active < 0 || n_active > e->d.G) { set_err(e->err, "n_active=%d out of range [0,%d]", n_active, e->d.G); return C4_EINVAL; }
+    if ((color0 == nullptr) != (color1 == nullptr)) { set_err(e->err, "color0/color1 must both be given or both NULL"); return C4_EINVAL; }
+    HIPCHK(e, hipSetDevice(e->device));
+    uint64_t *d0 = nullptr, *d1 = nullptr;
+    if (color0) {
+        for (int i = 0; i < n_active; ++i)
+            if (position_status(color0[i], color1[i]) != ST_FRESH || (color0[i] & color1[i])) {
+                set_err(e->err, "start position %d is decided or inconsistent (search on a finished board is an error in the reference too)", i);
+                return C4_EINVAL;
+            }
+        HIPCHK(e, hipMalloc((void **)&d0, sizeof(uint64_t) * (size_t)e->d.G));
+        HIPCHK(e, hipMalloc((void **)&d1, sizeof(uint64_t) * (size_t)e->d.G));
+        HIPCHK(e, hipMemcpyAsync(d0, color0, sizeof(uint64_t) * (size_t)n_active, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(e, hipMemcpyAsync(d1, color1, sizeof(uint64_t) * (size_t)n_active, hipMemcpyHostToDevice, e->stream));
+    }
+    int na = n_active;
+    if (e->d.games_target >= 0 && !e->d.stop_after_move && na > e->d.games_target) na = (int)e->d.games_target;
+    hipLaunchKernelGGL(c4_reset_kernel, dim3((e->d.G + 255) / 256), dim3(256), 0, e->stream, e->d, d0, d1, na);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (d0) (void)hipFree(d0);
+    if (d1) (void)hipFree(d1);
+    std::fill(e->drained_tag.begin(), e->drained_tag.end(), -1LL);
+    e->launches = 0;
+    return C4_OK;
+}
+
+int c4_set_tapes(c4_engine *e, const double *gamma_noise, const double *uniforms, int32_t n_games)
+{
+    if (!e || n_games <= 0 || !gamma_noise || !uniforms) { if (e) set_err(e->err, "c4_set_tapes: bad argument"); return C4_EINVAL; }
+    if (!e->d.rng_tape) { set_err(e->err, "engine was not created with C4_RNG_TAPE"); return C4_ESTATE; }
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->tape_noise) (void)hipFree(e->tape_noise);
+    if (e->tape_u) (void)hipFree(e->tape_u);
+    e->tape_noise = e->tape_u = nullptr;
+    HIPCHK(e, hipMalloc((void **)&e->tape_noise, sizeof(double) * 42 * 7 * (size_t)n_games));
+    HIPCHK(e, hipMalloc((void **)&e->tape_u, sizeof(double) * 42 * (size_t)n_games));
+    HIPCHK(e, hipMemcpy(e->tape_noise, gamma_noise, sizeof(double) * 42 * 7 * (size_t)n_games, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->tape_u, uniforms, sizeof(double) * 42 * (size_t)n_games, hipMemcpyHostToDevice));
+    e->d.noise_tape = e->tape_noise;
+    e->d.u_tape = e->tape_u;
+    e->d.tape_games = n_games;
+    return C4_OK;
+}
+
+int c4_step(c4_engine *e, const void *values_dev, const void *priors_dev, void *planes_dev)
+{
+    if (!e) return C4_EINVAL;
+    if (e->d.rng_tape && (e->d.use_noise || e->d.nsm > 0) && !e->d.noise_tape) { set_err(e->err, "C4_RNG_TAPE engine needs c4_set_tapes before stepping"); return C4_ESTATE; }
+    if (e->cfg.eval_mode != C4_EVAL_CENTRE && e->launches > 0 && (!values_dev || !priors_dev)) { set_err(e->err, "c4_step: values/priors are required after the first step"); return C4_EINVAL; }
+    const dim3 grid((e->d.G + SLOTS_PER_BLOCK - 1) / SLOTS_PER_BLOCK), block(BLOCK);
+    switch (e->cfg.eval_mode) {
+    case C4_EVAL_EXTERNAL_F32:
+        hipLaunchKernelGGL(c4_step_kernel<C4_EVAL_EXTERNAL_F32>, grid, block, 0, e->stream, e->d, values_dev, priors_dev, planes_dev);
+        break;
+    case C4_EVAL_EXTERNAL_F64:
+        hipLaunchKernelGGL(c4_step_kernel<C4_EVAL_EXTERNAL_F64>, grid, block, 0, e->stream, e->d, values_dev, priors_dev, planes_dev);
+        break;
+    default:
+        hipLaunchKernelGGL(c4_step_kernel<C4_EVAL_CENTRE>, grid, block, 0, e->stream, e->d, values_dev, priors_dev, planes_dev);
+        break;
+    }
+    HIPCHK(e, hipGetLastError());
+    e->launches += 1;
+    return C4_OK;
+}
+
+int c4_get_stats(c4_engine *e, c4_stats *out)
+{
+    if (!e || !out) return C4_EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    const size_t G = (size_t)e->d.G;
+    std::vector<uint64_t> s(G * N_STATS);
+    std::vector<int32_t> stt(G);
+    HIPCHK(e, hipMemcpy(s.data(), e->d.stats, s.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(stt.data(), e->d.state, G * sizeof(int32_t), hipMemcpyDeviceToHost));
+    SlotStats t = {};
+    uint64_t *tp = (uint64_t *)&t;
+    for (size_t g = 0; g < G; ++g)
+        for (int i = 0; i < N_STATS; ++i) tp[i] += s[g * N_STATS + i];
+    memset(out, 0, sizeof(*out));
+    out->simulations = (int64_t)t.sims;
+    out->expansions = (int64_t)t.expansions;
+    out->children_created = (int64_t)t.children;
+    out->terminal_sims = (int64_t)t.terminal_sims;
+    out->leaf_evals = (int64_t)t.leaf_evals;
+    out->depth_sum = (int64_t)t.depth_sum;
+    out->moves = (int64_t)t.moves;
+    out->games_started = (int64_t)t.games_started;
+    out->games_finished = (int64_t)t.games_finished;
+    out->capped_slots = (int64_t)t.capped;
+    out->launches = e->launches;
+    for (size_t g = 0; g < G; ++g) out->active_slots += stt[g] == SLOT_ACTIVE;
+    return C4_OK;
+}
+
+int c4_run_centre(c4_engine *e, int32_t max_launches)
+{
+    if (!e) return C4_EINVAL;
+    if (e->cfg.eval_mode != C4_EVAL_CENTRE) { set_err(e->err, "c4_run_centre needs C4_EVAL_CENTRE"); return C4_ESTATE; }
+    for (int i = 0; i < max_launches; ++i) {
+        int rc = c4_step(e, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+        c4_stats s;
+        rc = c4_get_stats(e, &s);
+        if (rc) return rc;
+        if (s.active_slots == 0) return C4_OK;
+    }
+    return C4_OK;
+}
+
+int c4_leaf_buffers(c4_engine *e, const uint64_t **c0, const uint64_t **c1, const int32_t **has_leaf)
+{
+    if (!e) return C4_EINVAL;
+    if (c0) *c0 = e->d.leaf_c0;
+    if (c1) *c1 = e->d.leaf_c1;
+    if (has_leaf) *has_leaf = e->d.has_leaf;
+    return C4_OK;
+}
+
+int c4_read_leaves(c4_engine *e, uint64_t *c0, uint64_t *c1, int32_t *has_leaf)
+{
+    if (!e || !c0 || !c1 || !has_leaf) return C4_EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    const size_t G = (size_t)e->d.G;
+    HIPCHK(e, hipMemcpy(c0, e->d.leaf_c0, G * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(c1, e->d.leaf_c1, G * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(has_leaf, e->d.has_leaf, G * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return C4_OK;
+}
+
+int c4_read_roots(c4_engine *e, c4_root_result *out)
+{
+    if (!e || !out) return C4_EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    c4_root_result *dout = nullptr;
+    const size_t G = (size_t)e->d.G;
+    HIPCHK(e, hipMalloc((void **)&dout, G * sizeof(c4_root_result)));
+    hipLaunchKernelGGL(c4_gather_roots_kernel, dim3((e->d.G + 63) / 64), dim3(64), 0, e->stream, e->d, dout);
+    hipError_t r = hipGetLastError();
+    if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+    if (r == hipSuccess) r = hipMemcpy(out, dout, G * sizeof(c4_root_result), hipMemcpyDeviceToHost);
+    (void)hipFree(dout);
+    HIPCHK(e, r);
+    return C4_OK;
+}
+
+int c4_drain_games(c4_engine *e, c4_game_record *out, int32_t cap, int32_t *n_out)
+{
+    if (!e || !out || !n_out || cap < 0) return C4_EINVAL;
+    *n_out = 0;
+    const size_t R = (size_t)e->d.rec_cap;
+    if (R == 0) return C4_OK;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    std::vector<int32_t> len(R), res(R);
+    std::vector<long long> tag(R);
+    HIPCHK(e, hipMemcpy(len.data(), e->d.game_len, R * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(res.data(), e->d.game_result, R * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(tag.data(), e->d.game_tag, R * sizeof(long long), hipMemcpyDeviceToHost));
+    // finished + not yet drained, by game id
+    std::vector<std::pair<long long, size_t>> ready;
+    for (size_t r = 0; r < R; ++r)
+        if (len[r] > 0 && tag[r] >= 0 && e->drained_tag[r] != tag[r]) ready.push_back({tag[r], r});
+    std::sort(ready.begin(), ready.end());
+    std::vector<uint64_t> b0(42), b1(42);
+    std::vector<int32_t> mv(42);
+    std::vector<double> val(42), pol(42 * 7);
+    int n = 0;
+    for (auto &pr : ready) {
+        if (n >= cap) break;
+        const size_t r = pr.second;
+        HIPCHK(e, hipMemcpy(b0.data(), e->d.rec_c0 + r * 42, 42 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(b1.data(), e->d.rec_c1 + r * 42, 42 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(mv.data(), e->d.rec_move + r * 42, 42 * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(val.data(), e->d.rec_value + r * 42, 42 * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(pol.data(), e->d.rec_policy + r * 42 * 7, 42 * 7 * sizeof(double), hipMemcpyDeviceToHost));
+        c4_game_record &g = out[n];
+        memset(&g, 0, sizeof(g));
+        g.game_id = pr.first;
+        g.length = len[r];
+        g.result = res[r];
+        for (int i = 0; i < len[r] && i < 42; ++i) {
+            g.color0[i] = b0[i];
+            g.color1[i] = b1[i];
+            g.move[i] = mv[i];
+            g.value[i] = val[i];
+            for (int k = 0; k < 7; ++k) g.policy[i][k] = pol[i * 7 + k];
+        }
+        e->drained_tag[r] = pr.first;
+        ++n;
+    }
+    *n_out = n;
+    return C4_OK;
+}
+
+// ---------------------------------------------------------------- pure board functions
+#define BOARD_PROLOGUE()                                   \
+    if (n < 0) { set_err(g_err, "n < 0"); return C4_EINVAL; } \
+    int rc = check_device(device, g_err);                  \
+    if (rc) return rc;                                     \
+    if (n == 0) return C4_OK;                              \
+    hipError_t r = hipSuccess;                             \
+    Scratch sc;
+
+#define BOARD_EPILOGUE()                                                                    \
+    if (r != hipSuccess) { set_err(g_err, "HIP failure: %s", hipGetErrorString(r)); return C4_EDEVICE; } \
+    return C4_OK;
+
+int c4_board_make_move(int device, const uint64_t *c0, const uint64_t *c1, const int32_t *col, int32_t n,
+                       uint64_t *o0, uint64_t *o1, int32_t *result)
+{
+    if (!c0 || !c1 || !col || !o0 || !o1 || !result) { set_err(g_err, "null argument"); return C4_EINVAL; }
+    BOARD_PROLOGUE();
+    for (int i = 0; i < n; ++i)
+        if (col[i] < 0 || col[i] >= 7) { set_err(g_err, "column %d out of range at %d", col[i], i); return C4_EINVAL; }
+    uint64_t *d0 = sc.up(c0, n, r), *d1 = sc.up(c1, n, r);
+    int32_t *dc = sc.up(col, n, r);
+    uint64_t *e0 = sc.up<uint64_t>(nullptr, n, r), *e1 = sc.up<uint64_t>(nullptr, n, r);
+    int32_t *dr = sc.up<int32_t>(nullptr, n, r);
+    if (r == hipSuccess) {
+        hipLaunchKernelGGL(k_make_move, dim3((n + 255) / 256), dim3(256), 0, 0, d0, d1, dc, n, e0, e1, dr);
+        r = hipGetLastError();
+    }
+    if (r == hipSuccess) r = hipMemcpy(o0, e0, sizeof(uint64_t) * n, hipMemcpyDeviceToHost);
+    if (r == hipSuccess) r = hipMemcpy(o1, e1, sizeof(uint64_t) * n, hipMemcpyDeviceToHost);
+    if (r == hipSuccess) r = hipMemcpy(result, dr, sizeof(int32_t) * n, hipMemcpyDeviceToHost);
+    BOARD_EPILOGUE();
+}
+
+int c4_board_wins(int device, const uint64_t *stones, int32_t n, int32_t *out)
+{
+    if (!stones || !out) { set_err(g_err, "null argument"); return C4_EINVAL; }
+    BOARD_PROLOGUE();
+    uint64_t *ds = sc.up(stones, n, r);
+    int32_t *dout = sc.up<int32_t>(nullptr, n, r);
+    if (r == hipSuccess) {
+        hipLaunchKernelGGL(k_wins, dim3((n + 255) / 256), dim3(256), 0, 0, ds, n, dout);
+        r = hipGetLastError();
+    }
+    if (r == hipSuccess) r = hipMemcpy(out, dout, sizeof(int32_t) * n, hipMemcpyDeviceToHost);
+    BOARD_EPILOGUE();
+}
+
+int c4_board_valid_mask(int device, const uint64_t *c0, const uint64_t *c1, int32_t n, int32_t *out)
+{
+    if (!c0 || !c1 || !out) { set_err(g_err, "null argument"); return C4_EINVAL; }
+    BOARD_PROLOGUE();
+    uint64_t *d0 = sc.up(c0, n, r), *d1 = sc.up(c1, n, r);
+    int32_t *dout = sc.up<int32_t>(nullptr, n, r);
+    if (r == hipSuccess) {
+        hipLaunchKernelGGL(k_valid_mask, dim3((n + 255) / 256), dim3(256), 0, 0, d0, d1, n, dout);
+        r = hipGetLastError();
+    }
+    if (r == hipSuccess) r = hipMemcpy(out, dout, sizeof(int32_t) * n, hipMemcpyDeviceToHost);
+    BOARD_EPILOGUE();
+}
+
+int c4_board_planes(int device, const uint64_t *c0, const uint64_t *c1, int32_t n, float *out)
+{
+    if (!c0 || !c1 || !out) { set_err(g_err, "null argument"); return C4_EINVAL; }
+    BOARD_PROLOGUE();
+    uint64_t *d0 = sc.up(c0, n, r), *d1 = sc.up(c1, n, r);
+    float *dout = sc.up<float>(nullptr, (size_t)n * 126, r);
+    if (r == hipSuccess) {
+        const size_t tot = (size_t)n * 126;
+        hipLaunchKernelGGL(k_planes, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, d0, d1, n, dout);
+        r = hipGetLastError();
+    }
+    if (r == hipSuccess) r = hipMemcpy(out, dout, sizeof(float) * (size_t)n * 126, hipMemcpyDeviceToHost);
+    BOARD_EPILOGUE();
+}
+
+int c4_board_fliplr(int device, const uint64_t *c0, const uint64_t *c1, int32_t n, uint64_t *o0, uint64_t *o1)
+{
+    if (!c0 || !c1 || !o0 || !o1) { set_err(g_err, "null argument"); return C4_EINVAL; }
+    BOARD_PROLOGUE();
+    uint64_t *d0 = sc.up(c0, n, r), *d1 = sc.up(c1, n, r);
+    uint64_t *e0 = sc.up<uint64_t>(nullptr, n, r), *e1 = sc.up<uint64_t>(nullptr, n, r);
+    if (r == hipSuccess) {
+        hipLaunchKernelGGL(k_fliplr, dim3((n + 255) / 256), dim3(256), 0, 0, d0, d1, n, e0, e1);
+        r = hipGetLastError();
+    }
+    if (r == hipSuccess) r = hipMemcpy(o0, e0, sizeof(uint64_t) * n, hipMemcpyDeviceToHost);
+    if (r == hipSuccess) r = hipMemcpy(o1, e1, sizeof(uint64_t) * n, hipMemcpyDeviceToHost);
+    BOARD_EPILOGUE();
+}
+
+int c4_board_centre_value(int device, const uint64_t *c0, const uint64_t *c1, int32_t n, double *out)
+{
+    if (!c0 || !c1 || !out) { set_err(g_err, "null argument"); return C4_EINVAL; }
+    BOARD_PROLOGUE();
+    uint64_t *d0 = sc.up(c0, n, r), *d1 = sc.up(c1, n, r);
+    double *dout = sc.up<double>(nullptr, n, r);
+    if (r == hipSuccess) {
+        hipLaunchKernelGGL(k_centre, dim3((n + 255) / 256), dim3(256), 0, 0, d0, d1, n, dout);
+        r = hipGetLastError();
+    }
+    if (r == hipSuccess) r = hipMemcpy(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost);
+    BOARD_EPILOGUE();
+}
+
+}  // extern "C"

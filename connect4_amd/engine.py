@@ -1,0 +1,200 @@
+"""Thin object wrapper over the C ABI (connect4_amd/_lib.py -> libc4engine.so).
+
+Host plumbing only: numpy for host arrays, torch tensors only as device buffers whose
+`data_ptr()` is handed across the ABI.  All search work happens in the HIP kernels.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+class Engine:
+    """One engine per GPU per process; not thread safe (one host thread drives it)."""
+
+    def __init__(self, n_slots, simulations, pb_c_base=19652, pb_c_init=1.25,
+                 root_dirichlet_alpha=0.0, root_exploration_fraction=0.0, num_sampling_moves=0,
+                 eval_mode=L.EVAL_EXTERNAL_F32, rng_mode=L.RNG_PHILOX, seed=0, stop_after_move=False,
+                 games_target=-1, record_capacity_games=0, max_inner_iters=0,
+                 planes_dtype=L.PLANES_F32, device=0):
+        self._lib = L.load()
+        self.cfg = L.Config()
+        self.cfg.abi_version = L.ABI_VERSION
+        self.cfg.n_slots = int(n_slots)
+        self.cfg.simulations = int(simulations)
+        self.cfg.pb_c_base = int(pb_c_base)
+        self.cfg.pb_c_init = float(pb_c_init)
+        self.cfg.root_dirichlet_alpha = float(root_dirichlet_alpha)
+        self.cfg.root_exploration_fraction = float(root_exploration_fraction)
+        self.cfg.num_sampling_moves = int(num_sampling_moves)
+        self.cfg.eval_mode = int(eval_mode)
+        self.cfg.rng_mode = int(rng_mode)
+        self.cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.cfg.stop_after_move = 1 if stop_after_move else 0
+        self.cfg.games_target = int(games_target)
+        self.cfg.record_capacity_games = int(record_capacity_games)
+        self.cfg.max_inner_iters = int(max_inner_iters)
+        self.cfg.planes_dtype = int(planes_dtype)
+        self.n_slots = int(n_slots)
+        self.device = int(device)
+        self._h = C.c_void_p()
+        L.check(self._lib.c4_engine_create(C.byref(self.cfg), self.device, C.byref(self._h)))
+
+    # -- lifecycle ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.c4_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        L.check(rc, self._h)
+
+    def set_stream(self, stream_handle):
+        self._check(self._lib.c4_set_stream(self._h, C.c_void_p(int(stream_handle))))
+
+    def reset(self, color0=None, color1=None, n_active=None):
+        if color0 is None:
+            n = self.n_slots if n_active is None else int(n_active)
+            self._check(self._lib.c4_reset(self._h, None, None, n))
+            return
+        c0, c1 = _u64(color0), _u64(color1)
+        n = len(c0) if n_active is None else int(n_active)
+        assert len(c0) == len(c1) >= n
+        self._check(self._lib.c4_reset(self._h, _ptr(c0, C.c_uint64), _ptr(c1, C.c_uint64), n))
+
+    def set_tapes(self, gamma_noise, uniforms):
+        """gamma_noise [games][42][7] raw Gamma(alpha,1) draws, uniforms [games][42] (u<0: best_move)."""
+        nz = np.ascontiguousarray(gamma_noise, dtype=np.float64)
+        u = np.ascontiguousarray(uniforms, dtype=np.float64)
+        n = nz.shape[0]
+        assert nz.shape == (n, 42, 7) and u.shape == (n, 42)
+        self._check(self._lib.c4_set_tapes(self._h, _ptr(nz, C.c_double), _ptr(u, C.c_double), n))
+
+    # -- hot path ----------------------------------------------------------------------------
+    def step_ptrs(self, values_ptr, priors_ptr, planes_ptr):
+        self._check(self._lib.c4_step(self._h, C.c_void_p(values_ptr or 0), C.c_void_p(priors_ptr or 0),
+                                      C.c_void_p(planes_ptr or 0)))
+
+    def step(self, values=None, priors=None, planes=None):
+        """values/priors/planes are torch device tensors (or None)."""
+        self.step_ptrs(0 if values is None else values.data_ptr(),
+                       0 if priors is None else priors.data_ptr(),
+                       0 if planes is None else planes.data_ptr())
+
+    def run_centre(self, max_launches=64):
+        self._check(self._lib.c4_run_centre(self._h, int(max_launches)))
+
+    def leaf_buffers(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._check(self._lib.c4_leaf_buffers(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def read_leaves(self):
+        c0 = np.zeros(self.n_slots, dtype=np.uint64)
+        c1 = np.zeros(self.n_slots, dtype=np.uint64)
+        has = np.zeros(self.n_slots, dtype=np.int32)
+        self._check(self._lib.c4_read_leaves(self._h, _ptr(c0, C.c_uint64), _ptr(c1, C.c_uint64),
+                                             _ptr(has, C.c_int32)))
+        return c0, c1, has
+
+    # -- read-out ----------------------------------------------------------------------------
+    def stats(self):
+        s = L.Stats()
+        self._check(self._lib.c4_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def read_roots(self):
+        out = (L.RootResult * self.n_slots)()
+        self._check(self._lib.c4_read_roots(self._h, out))
+        return out
+
+    def drain_games(self, cap=None):
+        cap = int(cap if cap is not None else max(1, self.cfg.record_capacity_games or 2 * self.n_slots))
+        out = (L.GameRecord * cap)()
+        n = C.c_int32()
+        self._check(self._lib.c4_drain_games(self._h, out, cap, C.byref(n)))
+        return [out[i] for i in range(n.value)]
+
+
+# -- pure board functions executed by the device code ------------------------------------------
+def _run_board(fn_name, device, inputs, outputs):
+    lib = L.load()
+    args = [device]
+    for a, ct in inputs:
+        args.append(_ptr(a, ct))
+    n = len(inputs[0][0])
+    args.append(n)
+    for a, ct in outputs:
+        args.append(_ptr(a, ct))
+    L.check(getattr(lib, fn_name)(*args))
+
+
+def board_make_move(color0, color1, cols, device=0):
+    c0, c1 = _u64(color0), _u64(color1)
+    col = np.ascontiguousarray(cols, dtype=np.int32)
+    o0, o1 = np.zeros_like(c0), np.zeros_like(c1)
+    res = np.zeros(len(c0), dtype=np.int32)
+    lib = L.load()
+    L.check(lib.c4_board_make_move(device, _ptr(c0, C.c_uint64), _ptr(c1, C.c_uint64), _ptr(col, C.c_int32),
+                                   len(c0), _ptr(o0, C.c_uint64), _ptr(o1, C.c_uint64), _ptr(res, C.c_int32)))
+    return o0, o1, res
+
+
+def board_wins(stones, device=0):
+    s = _u64(stones)
+    out = np.zeros(len(s), dtype=np.int32)
+    L.check(L.load().c4_board_wins(device, _ptr(s, C.c_uint64), len(s), _ptr(out, C.c_int32)))
+    return out
+
+
+def board_valid_mask(color0, color1, device=0):
+    c0, c1 = _u64(color0), _u64(color1)
+    out = np.zeros(len(c0), dtype=np.int32)
+    L.check(L.load().c4_board_valid_mask(device, _ptr(c0, C.c_uint64), _ptr(c1, C.c_uint64), len(c0),
+                                         _ptr(out, C.c_int32)))
+    return out
+
+
+def board_planes(color0, color1, device=0):
+    c0, c1 = _u64(color0), _u64(color1)
+    out = np.zeros((len(c0), 3, 6, 7), dtype=np.float32)
+    L.check(L.load().c4_board_planes(device, _ptr(c0, C.c_uint64), _ptr(c1, C.c_uint64), len(c0),
+                                     _ptr(out, C.c_float)))
+    return out
+
+
+def board_fliplr(color0, color1, device=0):
+    c0, c1 = _u64(color0), _u64(color1)
+    o0, o1 = np.zeros_like(c0), np.zeros_like(c1)
+    L.check(L.load().c4_board_fliplr(device, _ptr(c0, C.c_uint64), _ptr(c1, C.c_uint64), len(c0),
+                                     _ptr(o0, C.c_uint64), _ptr(o1, C.c_uint64)))
+    return o0, o1
+
+
+def board_centre_value(color0, color1, device=0):
+    c0, c1 = _u64(color0), _u64(color1)
+    out = np.zeros(len(c0), dtype=np.float64)
+    L.check(L.load().c4_board_centre_value(device, _ptr(c0, C.c_uint64), _ptr(c1, C.c_uint64), len(c0),
+                                           _ptr(out, C.c_double)))
+    return out

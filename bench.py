@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: self-play games/sec + MCTS node-expansions/sec at 800 sims/move.
+
+Workload (BASELINE.json configs[1]): 4096 parallel self-play games per GPU, 800 simulations per
+move, random-init residual policy/value net (32 filters, 3 residual blocks), self-play settings
+(Dirichlet alpha 0.3, fraction 0.25, 6 sampled opening moves).  Synthetic data: games start from the
+empty board, weights are seeded random-init.
+
+A "step" = one rollout step of the hot path over the whole batch: the HIP tree kernel (apply the
+previous leaf evaluations + backup, PUCT descent, expansion, move choice / re-rooting, leaf emission)
+followed by the leaf-batch network forward.  Every live game performs >= 1 simulation per step.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N>1: launched by torch.distributed.run, one rank per GPU; games shard across ranks (disjoint RNG
+streams seed+rank), there is NO collective inside the rollout path (weak scaling).  Rank 0 prints ONE
+JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+FP32_MATRIX_PEAK_TF = 157.3  # fp32-in MFMA / vector peak
+BF16_MFMA_PEAK_TF = 2500.0   # dense
+NET_MFLOP_PER_POSITION = 4.74  # BASELINE.md section 4 (32 filters, 3 residual blocks)
+
+
+def tree_bytes_per_sim(mean_depth):
+    # BASELINE.md section 4 / SURVEY.md 8d: algorithmic bytes per simulation = 136*D + 332
+    return 136.0 * mean_depth + 332.0
+
+
+def cpu_baseline(state_dict, sims, seconds, n_games):
+    """The oracle's lock-step many-game self-play (game_pool.py + inference_server.py shape) with
+    the same net evaluated by PyTorch on the host cores.  Checker timed as a baseline -- never the
+    product path."""
+    import numpy as np
+    import torch
+    from connect4_amd.net import PolicyValueNet
+    from oracle import c4oracle as oc
+
+    # a one-GPU box share is 16 host threads; more threads than that oversubscribes the tiny batch
+    cores = min(os.cpu_count() or 1, 16)
+    oc.set_threads(cores)
+    torch.set_num_threads(cores)
+    net = PolicyValueNet(PolicyValueNet.config_from_state_dict(state_dict))
+    net.load_state_dict(state_dict)
+    net.eval()
+    cfg = oc.make_config(sims, root_dirichlet_alpha=0.3, root_exploration_fraction=0.25, num_sampling_moves=6)
+    pool = oc.Pool(cfg, n_games, seed=0)
+    t0 = time.time()
+    steps = 0
+    with torch.no_grad():
+        while time.time() - t0 < seconds:
+            planes = pool.collect()
+            v, p = net(torch.from_numpy(planes.astype(np.float32)))
+            pool.apply(v.numpy(), p.numpy())
+            steps += 1
+    dt = time.time() - t0
+    st = pool.stats()
+    pool.close()
+    return dict(value=st["expansions"] / dt, unit="node-expansions/s", cores=cores, kind="port",
+                sims_per_s=st["sims"] / dt, games_per_s=st["games"] / dt,
+                sample="%d lock-step games x %d steps (%.1f s) of the same workload, oracle C MCTS (OpenMP) + "
+                       "PyTorch CPU net on %d threads" % (n_games, steps, dt, cores))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24000)
+    ap.add_argument("--warmup", type=int, default=2400)
+    ap.add_argument("--slots", type=int, default=4096, help="parallel games per GPU")
+    ap.add_argument("--sims", type=int, default=800)
+    ap.add_argument("--net-dtype", default="f32", choices=["f32", "f16", "bf16"])
+    ap.add_argument("--steps-per-graph", type=int, default=8)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=200, help="event-timed eager steps for the roofline")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as entry
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+        dist.barrier()   # rank 0 has finished building
+    torch.cuda.set_device(local_rank)
+
+    from connect4_amd.config import MCTSConfig
+    from connect4_amd.net import InferenceNet, NetConfig, random_init_state_dict
+    from connect4_amd.selfplay import SelfPlay
+
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.net_dtype]
+    sd = random_init_state_dict(NetConfig(), seed=0)
+    net = InferenceNet(sd, device="cuda:%d" % local_rank, dtype=tdt)
+    sp = SelfPlay(net, args.slots, MCTSConfig.self_play(args.sims), seed=rank, device=local_rank,
+                  games_target=-1, record_capacity_games=2 * args.slots, planes_dtype=tdt,
+                  use_graph=not args.no_graph, steps_per_graph=args.steps_per_graph)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    sp.run_steps(args.warmup)
+    sp.synchronize()
+    s0 = sp.stats()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sp.run_steps(args.steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    s1 = sp.stats()
+    delta = {k: s1[k] - s0[k] for k in s1}
+
+    # max elapsed over ranks, sum of units over ranks
+    tens = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    units = torch.tensor([delta["expansions"], delta["simulations"], delta["games_finished"], delta["moves"],
+                          delta["leaf_evals"], delta["terminal_sims"], delta["depth_sum"], delta["children_created"]],
+                         dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tens, op=dist.ReduceOp.MAX)
+        dist.all_reduce(units, op=dist.ReduceOp.SUM)
+    elapsed = float(tens.item())
+    exps, sims, games, moves, evals, term, depth_sum, children = [float(x) for x in units.tolist()]
+
+    # ---- event-timed eager segment: per-kernel averages for the roofline (same stream as the kernels)
+    prof = None
+    if rank == 0 and args.profile_steps > 0:
+        p0 = sp.stats()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.profile_steps)]
+        stream = torch.cuda.current_stream()
+        sp.engine.set_stream(stream.cuda_stream)
+        for a, b, c in ev:
+            a.record(stream)
+            sp.engine.step(sp.values, sp.priors, sp.planes)
+            b.record(stream)
+            v, p = sp.net(sp.planes)
+            sp.values.copy_(v)
+            sp.priors.copy_(p)
+            c.record(stream)
+            sp.steps_done += 1
+        torch.cuda.synchronize()
+        p1 = sp.stats()
+        tree_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev)
+        net_ms = sum(b.elapsed_time(c) for _, b, c in ev) / len(ev)
+        psims = p1["simulations"] - p0["simulations"]
+        pdepth = (p1["depth_sum"] - p0["depth_sum"]) / max(1, psims)
+        sims_per_launch = psims / len(ev)
+        tree_bytes = tree_bytes_per_sim(pdepth) * sims_per_launch
+        prof = dict(tree_ms=tree_ms, net_ms=net_ms, sims_per_launch=sims_per_launch, mean_depth=pdepth,
+                    tree_bytes_per_launch=tree_bytes)
+
+    if rank == 0:
+        mean_depth = depth_sum / max(1.0, sims)
+        out = {
+            "metric": "mcts_node_expansions_per_sec",
+            "value": exps / elapsed,
+            "unit": "node-expansions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": {"f32": "f32", "f16": "f16", "bf16": "bf16"}[args.net_dtype],
+            "data": "synthetic",
+            "games_per_sec": games / elapsed,
+            "sims_per_sec": sims / elapsed,
+            "leaf_evals_per_sec": evals / elapsed,
+            "children_created_per_sec": children / elapsed,
+            "moves_per_sec": moves / elapsed,
+            "terminal_sim_fraction": term / max(1.0, sims),
+            "mean_leaf_depth": mean_depth,
+            "config": {
+                "workload": "%d parallel self-play games per GPU, %d sims/move, random-init resnet "
+                            "(32 filters, 3 residual blocks), %dxMI355X" % (args.slots, args.sims, world),
+                "slots_per_gpu": args.slots, "simulations": args.sims, "net": "32f-3res-4fc",
+                "net_dtype": args.net_dtype, "tree_dtype": "u64 bitboards, u32 visits, f64 value sums/priors",
+                "parallelism": "games sharded over %d GPU(s), no collective in the rollout path" % world,
+                "hip_graph": (not args.no_graph), "steps_per_graph": args.steps_per_graph,
+                "dirichlet_alpha": 0.3, "exploration_fraction": 0.25, "num_sampling_moves": 6,
+            },
+        }
+        if prof:
+            ach = prof["tree_bytes_per_launch"] / (prof["tree_ms"] * 1e-3) / 1e9
+            out["roofline"] = {
+                "kernel": "c4_step_kernel<EXTERNAL_F32> (tree walk: apply+backup, PUCT descent, expand, emit)",
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                "avg_launch_ms": prof["tree_ms"], "sims_per_launch": prof["sims_per_launch"],
+                "mean_depth": prof["mean_depth"], "algorithmic_bytes_per_launch": prof["tree_bytes_per_launch"],
+                "note": "dependent-load (latency) bound pointer chase; bytes = (136*D+332) per simulation",
+            }
+            tf = NET_MFLOP_PER_POSITION * 1e6 * args.slots / (prof["net_ms"] * 1e-3) / 1e12
+            peak = FP32_MATRIX_PEAK_TF if args.net_dtype == "f32" else BF16_MFMA_PEAK_TF
+            out["roofline_net"] = {
+                "kernel": "leaf-batch policy/value net forward (PyTorch-ROCm / MIOpen convs)",
+                "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                "avg_forward_ms": prof["net_ms"], "traffic": None,
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, args.sims, args.cpu_seconds, 256)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    sp.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,125 @@
+"""Device-resident self-play: the HIP rollout-step kernel and the leaf-batch network alternate on
+one HIP stream, captured as a HIP graph; no host round trip per simulation.
+
+Stands in for TrainingLoop._generate_games' process/thread/pipe scaffolding
+(oinkoink/neural/training.py:99-135, game_pool.py:15-42, inference_server.py:37-63): every slot is
+one sequential-MCTS game (no virtual loss, exactly the reference's per-tree semantics); the
+"inference server" is simply the next kernels on the stream.
+"""
+import time
+from typing import Callable, List, Optional
+
+import torch
+
+from . import _lib as L
+from .config import MCTSConfig
+from .engine import Engine
+from .training_game import GameData, game_data_from_record
+
+_PLANES = {torch.float32: L.PLANES_F32, torch.float16: L.PLANES_F16, torch.bfloat16: L.PLANES_BF16}
+
+
+class SelfPlay:
+    """n_slots concurrent games on one GPU.  `net` maps planes [n,3,6,7] -> (values [n] fp32 in
+    [0,1], priors [n,7] fp32) on the device (connect4_amd.net.InferenceNet or any callable)."""
+
+    def __init__(self, net: Callable, n_slots: int, config: MCTSConfig, seed: int = 0, device: int = 0,
+                 games_target: int = -1, record_capacity_games: int = 0, planes_dtype=torch.float32,
+                 use_graph: bool = True, steps_per_graph: int = 8, max_inner_iters: int = 0):
+        self.net = net
+        self.n_slots = n_slots
+        self.config = config
+        self.device = torch.device("cuda", device)
+        self.engine = Engine(n_slots, eval_mode=L.EVAL_EXTERNAL_F32, rng_mode=L.RNG_PHILOX, seed=seed,
+                             stop_after_move=False, games_target=games_target,
+                             record_capacity_games=record_capacity_games, max_inner_iters=max_inner_iters,
+                             planes_dtype=_PLANES[planes_dtype], device=device, **config.engine_kwargs())
+        with torch.cuda.device(self.device):
+            self.values = torch.zeros(n_slots, dtype=torch.float32, device=self.device)
+            self.priors = torch.full((n_slots, 7), 1.0 / 7.0, dtype=torch.float32, device=self.device)
+            self.planes = torch.zeros(n_slots, 3, 6, 7, dtype=planes_dtype, device=self.device)
+        self.steps_done = 0
+        self.steps_per_graph = max(1, steps_per_graph)
+        self._graph = None
+        self._use_graph = use_graph
+
+    # one rollout step = tree kernel (apply previous answers, select, emit leaves) + leaf evaluation
+    def _step_eager(self):
+        self.engine.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.engine.step(self.values, self.priors, self.planes)
+        v, p = self.net(self.planes)
+        self.values.copy_(v)
+        self.priors.copy_(p)
+
+    def _capture(self):
+        with torch.cuda.device(self.device):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):       # warm up allocator / MIOpen find before capture
+                for _ in range(3):
+                    self._step_eager()
+                    self.steps_done += 1
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(self.steps_per_graph):
+                    self._step_eager()
+            self._graph = g
+
+    def run_steps(self, k: int):
+        """Advance every slot by k rollout steps (asynchronous; call synchronize() to wait)."""
+        with torch.cuda.device(self.device):
+            if self._use_graph and self._graph is None and k >= self.steps_per_graph + 3:
+                self._capture()
+                k -= 3
+            if self._graph is not None:
+                self.engine.set_stream(torch.cuda.current_stream().cuda_stream)
+                while k >= self.steps_per_graph:
+                    self._graph.replay()
+                    k -= self.steps_per_graph
+                    self.steps_done += self.steps_per_graph
+            for _ in range(k):
+                self._step_eager()
+                self.steps_done += 1
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+    def stats(self):
+        s = self.engine.stats()
+        s["launches"] = self.steps_done
+        return s
+
+    def drain(self) -> List[GameData]:
+        return [game_data_from_record(r) for r in self.engine.drain_games()]
+
+    def close(self):
+        self._graph = None
+        self.engine.close()
+
+
+def generate_games(config: MCTSConfig, net: Callable, n_games: int, n_slots: Optional[int] = None,
+                   seed: int = 0, device: int = 0, planes_dtype=torch.float32, poll_steps: int = 256,
+                   use_graph: bool = True, timeout_s: float = 3600.0) -> List[GameData]:
+    """Play n_games self-play games and return them as GameData (training_game.py:42-67), the list
+    TrainingLoop._generate_games hands to data_storage.save (training.py:131-135)."""
+    n_slots = min(n_games, n_slots or 4096)
+    sp = SelfPlay(net, n_slots, config, seed=seed, device=device, games_target=n_games,
+                  record_capacity_games=n_games, planes_dtype=planes_dtype, use_graph=use_graph)
+    games: List[GameData] = []
+    t0 = time.time()
+    try:
+        while True:
+            sp.run_steps(poll_steps)
+            st = sp.stats()
+            if st["active_slots"] == 0:
+                break
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError("self-play did not finish: %r" % (st,))
+        games = sp.drain()
+    finally:
+        sp.close()
+    games.sort(key=lambda g: g.game_id)
+    assert len(games) == n_games, (len(games), n_games)
+    return games

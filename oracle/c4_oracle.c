@@ -15,6 +15,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* ------------------------------------------------------------------ board.py:9-32 constants */
 #define WIDTH 7
@@ -662,6 +665,15 @@ static double rng_gamma(uint64_t *s, double alpha)
         if (log(u) < 0.5 * x * x + d * (1.0 - v + log(v))) return boost * d * v;
     }
     return boost * d;
+}
+
+void c4o_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 
 c4o_pool *c4o_pool_new(const c4o_config *cfg, int n_games, uint64_t seed)

@@ -138,6 +138,7 @@ int c4o_eval_table(void *ctx, const c4o_board *b, double *value, double prior[7]
 
 /* ---- lock-step many-game driver for the CPU baseline (game_pool.py + inference_server.py shape) ---- */
 typedef struct c4o_pool c4o_pool;
+void      c4o_set_threads(int n);   /* OpenMP threads used by the pool */
 c4o_pool *c4o_pool_new(const c4o_config *cfg, int n_games, uint64_t seed);
 void      c4o_pool_free(c4o_pool *p);
 /* Advance every game until it needs a leaf evaluation; writes one board per game (planes uint8

@@ -133,6 +133,7 @@ def lib():
                                         C.POINTER(C.c_double), C.POINTER(C.c_double),
                                         C.POINTER(MoveRecord), C.POINTER(C.c_int),
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.c4o_set_threads.argtypes = [C.c_int]
         L.c4o_pool_new.argtypes = [C.POINTER(Config), C.c_int, C.c_uint64]
         L.c4o_pool_new.restype = C.c_void_p
         L.c4o_pool_free.argtypes = [C.c_void_p]
@@ -267,6 +268,10 @@ def selfplay_game(cfg, evaluator, noise_tape=None, u_tape=None):
                 values=[rec[i].value for i in range(n)],
                 policies=[list(rec[i].policy) for i in range(n)],
                 result=res.value, sims=sims.value, expansions=exps.value, evals=evals.value)
+
+
+def set_threads(n):
+    lib().c4o_set_threads(int(n))
 
 
 class Pool:

@@ -56,3 +56,15 @@ def game_data_from_record(rec) -> GameData:
                     None if math.isnan(v) else float(v), np.array(rec.policy[i], dtype=np.float64))
     gd.result = RESULT_FROM_CODE[int(rec.result)]
     return gd
+
+
+def training_game(player) -> GameData:
+    """One self-play game through the player protocol (training_game.py:8-19)."""
+    board = Board()
+    gd = GameData()
+    while board.result is None:
+        before = board.__copy__()
+        move, value, tree = player.make_move(board)
+        gd.add_move(before, move, value, tree.get_values_policy())
+    gd.result = board.result
+    return gd

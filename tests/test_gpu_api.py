@@ -1,0 +1,125 @@
+"""Drop-in API on the GPU: the reference's own player tests re-run against connect4_amd
+(tests/player_test.py:151-179 test_mcts_next_move: same positions, same configuration, same
+acceptance), np.random-seeded self-play reproducing the reference's games move for move, and the
+batched device-net path."""
+import numpy as np
+import pytest
+
+from conftest import load_json, load_npz, table_from_npz
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mcts_next_move_reference_cases():
+    from connect4_amd import evaluators
+    from connect4_amd.board import Board
+    from connect4_amd.mcts import MCTS, MCTSConfig
+    cases = load_json("ref_tests.json")["player"]
+    golden = {c["name"]: c for c in load_json("search_centre.json")}
+    for i, p in enumerate(cases):
+        plies = p["plies"]
+        board = Board.from_pieces(np.array(p["o"], dtype=np.bool_), np.array(p["x"], dtype=np.bool_))
+        computer = MCTS("mcts_test",
+                        MCTSConfig(simulations=7 ** plies + 1 if plies <= 6 else 2 ** plies, pb_c_init=9999),
+                        evaluators.Evaluator(evaluators.evaluate_centre_with_prior))
+        board_copy = board.__copy__()
+        move, value, tree = computer.make_move(board_copy)
+        assert move in p["ans"]
+        assert board_copy.age == board.age + 1                      # caller's board mutated in place
+        g = golden["player%d_testcfg" % i]
+        assert [c.data.search_value.visit_count if c.data.search_value else 0 for c in tree.root.children] == \
+            [n for n, s in zip(g["N"], g["status"]) if s != -2]
+        assert list(tree.get_values_policy()) == g["values_policy"]
+        assert list(tree.get_visit_count_policy()) == g["visit_policy"]
+        assert tree.best_move().name == g["best_move"] == move
+
+
+def test_seeded_training_game_reproduces_reference():
+    """np.random.seed(k) + training_game(MCTS(...)) gives the reference's game (same RNG calls)."""
+    from connect4_amd import evaluators
+    from connect4_amd.mcts import MCTS, MCTSConfig
+    from connect4_amd.training_game import training_game
+    for g in load_json("selfplay.json")[:3]:
+        cfg = MCTSConfig(**g["config"])
+        np.random.seed(g["seed"])
+        gd = training_game(MCTS("az", cfg, evaluators.Evaluator(evaluators.evaluate_centre_with_prior)))
+        assert gd.moves == g["moves"]
+        assert gd.result.value == g["result"]
+        assert [[b.color[0], b.color[1]] for b in gd.boards] == g["boards"]
+        assert gd.values == g["values"]
+        assert [list(p) for p in gd.priors] == g["policies"]
+        td = gd.data
+        assert td.values == [g["result"]] * len(g["moves"])
+
+
+def test_host_evaluator_float32_table():
+    """A generic Python evaluator returning float32 priors (what evaluate_nn gives, evaluators.py:41-44)
+    takes the float32 score path and reproduces the reference's net-driven search."""
+    from connect4_amd.board import Board
+    from connect4_amd.evaluators import Evaluator
+    from connect4_amd.mcts import MCTSConfig, search
+    npz = load_npz("search_net_tables.npz")
+    case = [c for c in load_json("search_net.json") if c["name"] == "net_random0_s200"][0]
+    c0, c1, v, p = table_from_npz(npz, case["name"])
+    table = {(int(a), int(b)): (float(vv), np.asarray(pp, dtype=np.float32)) for a, b, vv, pp in zip(c0, c1, v, p)}
+    calls = []
+
+    def evaluate_fn(board):
+        calls.append(board.to_int_tuple())
+        return table[board.to_int_tuple()]
+    ev = Evaluator(evaluate_fn)
+    tree = search(MCTSConfig(**case["config"]), Board.from_bits(case["board"]["c0"], case["board"]["c1"]), ev)
+    assert [c.data.search_value.visit_count if c.data.search_value else 0 for c in tree.root.children] == \
+        [n for n, s in zip(case["N"], case["status"]) if s != -2]
+    assert list(tree.get_values_policy()) == case["values_policy"]
+    assert len(set(calls)) == len(calls)      # memo table: each position evaluated once
+
+
+def test_device_net_search_and_generate_games():
+    import torch
+    from connect4_amd.board import Board
+    from connect4_amd.config import MCTSConfig
+    from connect4_amd.evaluators import DeviceNetEvaluator
+    from connect4_amd.mcts import MCTS
+    from connect4_amd.net import InferenceNet, random_init_state_dict
+    from connect4_amd.selfplay import generate_games
+    net = InferenceNet(random_init_state_dict(seed=0), device="cuda", dtype=torch.float32)
+    player = MCTS("dev", MCTSConfig(64), DeviceNetEvaluator(net))
+    boards = [Board() for _ in range(5)]
+    for b, mv in zip(boards, (0, 3, 3, 6, 2)):
+        b.make_move(mv)
+    outs = player.make_moves(boards)
+    for (move, value, tree), b in zip(outs, boards):
+        assert 0 <= move < 7 and b.age == 2
+        assert tree.root.data.search_value.visit_count == 65
+        assert abs(tree.get_values_policy().sum() - 1.0) < 1e-12
+    games = generate_games(MCTSConfig.self_play(32), net, n_games=24, n_slots=16, seed=3)
+    assert len(games) == 24 and sorted(g.game_id for g in games) == list(range(24))
+    for g in games:
+        b = Board()
+        for i, mv in enumerate(g.moves):
+            assert g.boards[i] == b and mv in b.valid_moves
+            assert abs(sum(g.priors[i]) - 1.0) < 1e-9
+            b.make_move(mv)
+        assert b.result == g.result and g.result is not None
+    # determinism: same seed, same games (per game id)
+    again = generate_games(MCTSConfig.self_play(32), net, n_games=24, n_slots=16, seed=3)
+    assert [g.moves for g in again] == [g.moves for g in games]
+
+
+def test_data_writer_matches_reference_native_to_pytorch():
+    """games -> data.pth tensors incl. left-right flip augmentation (data.py:78-105)."""
+    from connect4_amd.board import Board
+    from connect4_amd.data import games_to_arrays
+    from connect4_amd.training_game import GameData
+    from connect4_amd.utils import Result
+    npz = load_npz("selfplay_net_tables.npz")
+    for g in load_json("selfplay_net.json"):
+        gd = GameData()
+        for bb, mv, v, p in zip(g["boards"], g["moves"], g["values"], g["policies"]):
+            gd.add_move(Board.from_bits(*bb), mv, v, np.array(p))
+        gd.result = Result(g["result"])
+        boards, values, priors = games_to_arrays([gd], add_fliplr=True)
+        assert np.array_equal(boards.astype(np.uint8), npz[g["name"] + "__data_boards"])
+        assert np.array_equal(values, npz[g["name"] + "__data_values"])
+        assert np.array_equal(priors, npz[g["name"] + "__data_priors"])

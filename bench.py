@@ -79,7 +79,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2400)
     ap.add_argument("--slots", type=int, default=4096, help="parallel games per GPU")
     ap.add_argument("--sims", type=int, default=800)
-    ap.add_argument("--net-dtype", default="f32", choices=["f32", "f16", "bf16"])
+    ap.add_argument("--net", default="fused", choices=["fused", "torch"],
+                    help="fused: hand-written gfx950 MFMA kernel (fp16 storage, fp32 accumulate); torch: PyTorch-ROCm/MIOpen")
+    ap.add_argument("--net-dtype", default=None, choices=["f32", "f16", "bf16"], help="torch net only (default f32)")
     ap.add_argument("--steps-per-graph", type=int, default=8)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=200, help="event-timed eager steps for the roofline")
@@ -107,9 +109,18 @@ def main():
     from connect4_amd.net import InferenceNet, NetConfig, random_init_state_dict
     from connect4_amd.selfplay import SelfPlay
 
+    if args.net == "fused":
+        args.net_dtype = "f16"
+    elif args.net_dtype is None:
+        args.net_dtype = "f32"
     tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.net_dtype]
     sd = random_init_state_dict(NetConfig(), seed=0)
-    net = InferenceNet(sd, device="cuda:%d" % local_rank, dtype=tdt)
+    if args.net == "fused":
+        from connect4_amd.fused_net import FusedNet
+        net = FusedNet(sd, device=local_rank)
+        tdt = torch.float32   # planes are not materialised on this path
+    else:
+        net = InferenceNet(sd, device="cuda:%d" % local_rank, dtype=tdt)
     sp = SelfPlay(net, args.slots, MCTSConfig.self_play(args.sims), seed=rank, device=local_rank,
                   games_target=-1, record_capacity_games=2 * args.slots, planes_dtype=tdt,
                   use_graph=not args.no_graph, steps_per_graph=args.steps_per_graph)
@@ -151,11 +162,16 @@ def main():
         sp.engine.set_stream(stream.cuda_stream)
         for a, b, c in ev:
             a.record(stream)
-            sp.engine.step(sp.values, sp.priors, sp.planes)
-            b.record(stream)
-            v, p = sp.net(sp.planes)
-            sp.values.copy_(v)
-            sp.priors.copy_(p)
+            if args.net == "fused":
+                sp.engine.step(sp.values, sp.priors, None)
+                b.record(stream)
+                sp.net.forward_bitboards(sp._leaf_c0, sp._leaf_c1, sp.n_slots, sp.values, sp.priors, stream.cuda_stream)
+            else:
+                sp.engine.step(sp.values, sp.priors, sp.planes)
+                b.record(stream)
+                v, p = sp.net(sp.planes)
+                sp.values.copy_(v)
+                sp.priors.copy_(p)
             c.record(stream)
             sp.steps_done += 1
         torch.cuda.synchronize()
@@ -195,7 +211,7 @@ def main():
                 "workload": "%d parallel self-play games per GPU, %d sims/move, random-init resnet "
                             "(32 filters, 3 residual blocks), %dxMI355X" % (args.slots, args.sims, world),
                 "slots_per_gpu": args.slots, "simulations": args.sims, "net": "32f-3res-4fc",
-                "net_dtype": args.net_dtype, "tree_dtype": "u64 bitboards, u32 visits, f64 value sums/priors",
+                "net_impl": args.net, "net_dtype": args.net_dtype, "tree_dtype": "u64 bitboards, u32 visits, f64 value sums/priors",
                 "parallelism": "games sharded over %d GPU(s), no collective in the rollout path" % world,
                 "hip_graph": (not args.no_graph), "steps_per_graph": args.steps_per_graph,
                 "dirichlet_alpha": 0.3, "exploration_fraction": 0.25, "num_sampling_moves": 6,
@@ -214,7 +230,8 @@ def main():
             tf = NET_MFLOP_PER_POSITION * 1e6 * args.slots / (prof["net_ms"] * 1e-3) / 1e12
             peak = FP32_MATRIX_PEAK_TF if args.net_dtype == "f32" else BF16_MFMA_PEAK_TF
             out["roofline_net"] = {
-                "kernel": "leaf-batch policy/value net forward (PyTorch-ROCm / MIOpen convs)",
+                "kernel": ("c4_net_kernel (fused stem+tower+heads, v_mfma_f32_32x32x16_f16)" if args.net == "fused"
+                           else "leaf-batch policy/value net forward (PyTorch-ROCm / MIOpen convs)"),
                 "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                 "avg_forward_ms": prof["net_ms"], "traffic": None,
             }

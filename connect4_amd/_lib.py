@@ -60,6 +60,13 @@ class GameRecord(C.Structure):
                 ("value", C.c_double * 42), ("policy", (C.c_double * 7) * 42)]
 
 
+class NetDesc(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("filters", C.c_int32), ("n_residuals", C.c_int32), ("reserved", C.c_int32)] + \
+        [(n, C.POINTER(C.c_float)) for n in ("stem_w", "stem_b", "conv_w", "conv_b", "head_w", "head_b",
+                                             "vfc_w", "vfc_b", "vout_w", "pfc_w", "pfc_b")] + \
+        [("vout_b", C.c_float), ("w1", C.c_float), ("w2", C.c_float), ("reserved2", C.c_float)]
+
+
 _P = C.POINTER
 _u64p, _i32p, _f32p, _f64p = _P(C.c_uint64), _P(C.c_int32), _P(C.c_float), _P(C.c_double)
 
@@ -85,6 +92,10 @@ SIGNATURES = {
     "c4_board_planes": (C.c_int, [C.c_int, _u64p, _u64p, C.c_int32, _f32p]),
     "c4_board_fliplr": (C.c_int, [C.c_int, _u64p, _u64p, C.c_int32, _u64p, _u64p]),
     "c4_board_centre_value": (C.c_int, [C.c_int, _u64p, _u64p, C.c_int32, _f64p]),
+    "c4_net_create": (C.c_int, [C.c_int, _P(NetDesc), _P(C.c_void_p)]),
+    "c4_net_destroy": (C.c_int, [C.c_void_p]),
+    "c4_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "c4_net_last_error": (C.c_char_p, []),
 }
 
 _lib = None

@@ -1,0 +1,97 @@
+"""Host wrapper of the fused gfx950 network kernel (csrc/c4_net.hip) behind c4_net_* of the C ABI.
+
+``FusedNet(state_dict)`` folds BatchNorm (eval mode) and collapses the value head's Linear stack on
+the host (same algebra as connect4_amd.net.InferenceNet), hands plain float32 arrays across the ABI,
+and evaluates leaf batches straight from the engine's bitboard buffers:
+``net.forward_bitboards(c0_ptr, c1_ptr, n, values, priors)``.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .net import PolicyValueNet, _fold_bn
+
+
+class FusedNet:
+    from_bitboards = True
+
+    def __init__(self, state_dict, device: int = 0):
+        import torch
+        sd = {k: v.detach().cpu() for k, v in state_dict.items()}
+        cfg = PolicyValueNet.config_from_state_dict(sd)
+        self.config = cfg
+        self.device = device
+
+        def bn(prefix):
+            return (sd[prefix + ".weight"], sd[prefix + ".bias"], sd[prefix + ".running_mean"], sd[prefix + ".running_var"])
+
+        f32 = lambda t: np.ascontiguousarray(t.to(torch.float32).numpy())  # noqa: E731
+        stem_w, stem_b = _fold_bn(sd["body.0.0.weight"], None, *bn("body.0.1"))
+        cw, cb = [], []
+        for i in range(cfg.n_residuals):
+            p = "body.1.%d." % i
+            for j in (1, 2):
+                w, b = _fold_bn(sd[p + "conv%d.weight" % j], None, *bn(p + "batch_norm%d" % j))
+                cw.append(w)
+                cb.append(b)
+        vw, vb = _fold_bn(sd["value_head.conv1.weight"], sd["value_head.conv1.bias"], *bn("value_head.batch_norm"))
+        pw, pb = _fold_bn(sd["policy_head.conv1.weight"], sd["policy_head.conv1.bias"], *bn("policy_head.batch_norm"))
+        W = torch.eye(42, dtype=torch.float64)
+        bias = torch.zeros(42, dtype=torch.float64)
+        for i in range(cfg.n_fc_layers):
+            Wi = sd["value_head.fcN.%d.weight" % i].double()
+            W, bias = Wi @ W, Wi @ bias + sd["value_head.fcN.%d.bias" % i].double()
+        self._arrays = dict(
+            stem_w=f32(stem_w), stem_b=f32(stem_b),
+            conv_w=f32(torch.stack(cw)) if cw else np.zeros(1, np.float32),
+            conv_b=f32(torch.stack(cb)) if cb else np.zeros(1, np.float32),
+            head_w=f32(torch.cat([vw, pw], 0).reshape(3, cfg.filters)), head_b=f32(torch.cat([vb, pb], 0)),
+            vfc_w=f32(W), vfc_b=f32(bias), vout_w=f32(sd["value_head.fc1.weight"].reshape(42)),
+            pfc_w=f32(sd["policy_head.fc1.weight"]), pfc_b=f32(sd["policy_head.fc1.bias"]))
+        d = L.NetDesc()
+        d.channels, d.filters, d.n_residuals = cfg.channels, cfg.filters, cfg.n_residuals
+        for k, a in self._arrays.items():
+            setattr(d, k, a.ctypes.data_as(C.POINTER(C.c_float)))
+        d.vout_b = float(sd["value_head.fc1.bias"].reshape(-1)[0])
+        d.w1 = float(sd["value_head.w1"])
+        d.w2 = float(sd["value_head.w2"])
+        self._lib = L.load()
+        self._h = C.c_void_p()
+        rc = self._lib.c4_net_create(device, C.byref(d), C.byref(self._h))
+        if rc != L.OK:
+            raise L.EngineError(rc, (self._lib.c4_net_last_error() or b"").decode())
+
+    def forward_bitboards(self, c0_ptr, c1_ptr, n, values, priors, stream=None):
+        """values/priors: torch float32 device tensors; c0_ptr/c1_ptr: device addresses of uint64[n]."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(values.device).cuda_stream
+        rc = self._lib.c4_net_forward(self._h, C.c_void_p(stream), C.c_void_p(c0_ptr), C.c_void_p(c1_ptr), int(n),
+                                      C.c_void_p(values.data_ptr()), C.c_void_p(priors.data_ptr()))
+        if rc != L.OK:
+            raise L.EngineError(rc, (self._lib.c4_net_last_error() or b"").decode())
+
+    def evaluate_bits(self, color0, color1):
+        """Convenience for tests: numpy uint64 arrays -> (values, priors) numpy."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        c0 = torch.from_numpy(np.ascontiguousarray(color0, dtype=np.uint64).view(np.int64)).to(dev)
+        c1 = torch.from_numpy(np.ascontiguousarray(color1, dtype=np.uint64).view(np.int64)).to(dev)
+        n = c0.numel()
+        v = torch.zeros(n, dtype=torch.float32, device=dev)
+        p = torch.zeros(n, 7, dtype=torch.float32, device=dev)
+        self.forward_bitboards(c0.data_ptr(), c1.data_ptr(), n, v, p)
+        torch.cuda.synchronize(dev)
+        return v.cpu().numpy(), p.cpu().numpy()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.c4_net_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

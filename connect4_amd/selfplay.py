@@ -38,6 +38,8 @@ class SelfPlay:
             self.values = torch.zeros(n_slots, dtype=torch.float32, device=self.device)
             self.priors = torch.full((n_slots, 7), 1.0 / 7.0, dtype=torch.float32, device=self.device)
             self.planes = torch.zeros(n_slots, 3, 6, 7, dtype=planes_dtype, device=self.device)
+        self._bits = bool(getattr(net, "from_bitboards", False))   # fused kernel reads the leaf bitboards
+        self._leaf_c0, self._leaf_c1, _ = self.engine.leaf_buffers()
         self.steps_done = 0
         self.steps_per_graph = max(1, steps_per_graph)
         self._graph = None
@@ -45,7 +47,12 @@ class SelfPlay:
 
     # one rollout step = tree kernel (apply previous answers, select, emit leaves) + leaf evaluation
     def _step_eager(self):
-        self.engine.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.engine.set_stream(stream)
+        if self._bits:
+            self.engine.step(self.values, self.priors, None)
+            self.net.forward_bitboards(self._leaf_c0, self._leaf_c1, self.n_slots, self.values, self.priors, stream)
+            return
         self.engine.step(self.values, self.priors, self.planes)
         v, p = self.net(self.planes)
         self.values.copy_(v)

@@ -195,6 +195,33 @@ int c4_board_fliplr(int device, const uint64_t *color0, const uint64_t *color1, 
 /* evaluators.py:28-33 evaluate_centre (float64) */
 int c4_board_centre_value(int device, const uint64_t *color0, const uint64_t *color1, int32_t n, double *out);
 
+/* -- fused leaf-batch network (c4_net.hip) -------------------------------------------------- */
+/* Eval-mode forward of the reference's Net (oinkoink/neural/pytorch/model.py:120-134) as ONE
+ * gfx950 MFMA kernel reading the leaves' bitboards; stands in for ModelWrapper._call_list
+ * (model.py:269-282) + the InferenceServer round trip (inference_server.py:50-63).
+ * All weights are host float32 with BatchNorm already folded (eval mode):
+ *   stem_w [F][3][3][3], stem_b [F]            body.0 (model.py:20-31)
+ *   conv_w [2R][F][F][3][3], conv_b [2R][F]    residual blocks, conv1 then conv2 (model.py:36-55)
+ *   head_w [3][F], head_b [3]                  value 1x1 conv, then the 2 policy 1x1 channels
+ *   vfc_w [42][42], vfc_b [42]                 the activation-free Linear stack collapsed (model.py:69-70,83)
+ *   vout_w [42], vout_b                        value_head.fc1 (model.py:72,85)
+ *   pfc_w [7][84], pfc_b [7]                   policy_head.fc1 (model.py:104,113)
+ *   w1, w2                                     value_head.w1/w2 (model.py:74-75,88) */
+typedef struct {
+    int32_t channels, filters, n_residuals, reserved;
+    const float *stem_w, *stem_b, *conv_w, *conv_b, *head_w, *head_b;
+    const float *vfc_w, *vfc_b, *vout_w, *pfc_w, *pfc_b;
+    float vout_b, w1, w2, reserved2;
+} c4_net_desc;
+typedef struct c4_net c4_net;
+int c4_net_create(int device, const c4_net_desc *desc, c4_net **out);
+int c4_net_destroy(c4_net *net);
+/* values_dev float32[n] in [0,1] (o's side), priors_dev float32[n][7]; bitboards as emitted by
+ * c4_step (c4_leaf_buffers).  Asynchronous on hip_stream. */
+int c4_net_forward(c4_net *net, void *hip_stream, const uint64_t *color0_dev, const uint64_t *color1_dev,
+                   int32_t n, float *values_dev, float *priors_dev);
+const char *c4_net_last_error(void);
+
 int c4_abi_version(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,55 @@
+"""Fused gfx950 network kernel (csrc/c4_net.hip, through c4_net_* of the C ABI) vs
+  (a) the reference's ModelWrapper outputs on example_net.pth (tests/golden/net_golden.npz) and
+  (b) the fp32 PyTorch plan of the same weights on seeded random positions.
+Tolerance: fp16 storage / fp32 accumulation -> 2e-2 absolute on values and priors (stated; the
+kernel's measured error is printed)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz
+
+pytestmark = pytest.mark.gpu
+
+
+def random_positions(oracle, n, seed):
+    rng = np.random.RandomState(seed)
+    c0, c1 = [], []
+    while len(c0) < n:
+        b = oracle.Board.empty()
+        for _ in range(int(rng.randint(0, 42))):
+            m = b.valid_mask()
+            if not m:
+                break
+            b.make_move(int(rng.choice([c for c in range(7) if (m >> c) & 1])))
+        c0.append(b.key()[0])
+        c1.append(b.key()[1])
+    return np.array(c0, dtype=np.uint64), np.array(c1, dtype=np.uint64)
+
+
+def test_fused_net_vs_reference_golden():
+    from connect4_amd.fused_net import FusedNet
+    z = load_npz("net_golden.npz")
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w__")}
+    net = FusedNet(sd)
+    v, p = net.evaluate_bits(z["in_c0"], z["in_c1"])
+    print("fused vs reference golden: max |dv| %.3g  max |dp| %.3g" %
+          (np.abs(v - z["out_values"]).max(), np.abs(p - z["out_priors"]).max()))
+    np.testing.assert_allclose(v, z["out_values"], atol=2e-2, rtol=0)
+    np.testing.assert_allclose(p, z["out_priors"], atol=2e-2, rtol=0)
+    np.testing.assert_allclose(p.sum(1), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 4099])
+def test_fused_net_vs_pytorch_fp32(oracle, n):
+    from connect4_amd.engine import board_planes
+    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.net import InferenceNet, random_init_state_dict
+    sd = random_init_state_dict(seed=0)
+    c0, c1 = random_positions(oracle, n, seed=n)
+    ref = InferenceNet(sd, device="cuda", dtype=torch.float32)
+    rv, rp = ref(torch.from_numpy(board_planes(c0, c1)).cuda())
+    v, p = FusedNet(sd).evaluate_bits(c0, c1)
+    dv, dp = np.abs(v - rv.cpu().numpy()).max(), np.abs(p - rp.cpu().numpy()).max()
+    print("n=%d fused vs torch fp32: max |dv| %.3g  max |dp| %.3g" % (n, dv, dp))
+    assert dv < 2e-2 and dp < 2e-2

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fused network kernel: n positions, HIP-event timed."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--iters", type=int, default=200)
+    args = ap.parse_args()
+    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.net import InferenceNet, random_init_state_dict
+    from connect4_amd.engine import board_planes
+    sd = random_init_state_dict(seed=0)
+    net = FusedNet(sd)
+    rng = np.random.RandomState(0)
+    c0 = rng.randint(0, 2 ** 40, size=args.n).astype(np.uint64) & np.uint64(0x7EFDFBF7EFDF)
+    c1 = (rng.randint(0, 2 ** 40, size=args.n).astype(np.uint64) & np.uint64(0x7EFDFBF7EFDF)) & ~c0
+    d0 = torch.from_numpy(c0.view(np.int64)).cuda()
+    d1 = torch.from_numpy(c1.view(np.int64)).cuda()
+    v = torch.zeros(args.n, device="cuda")
+    p = torch.zeros(args.n, 7, device="cuda")
+    for _ in range(10):
+        net.forward_bitboards(d0.data_ptr(), d1.data_ptr(), args.n, v, p)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(args.iters):
+        net.forward_bitboards(d0.data_ptr(), d1.data_ptr(), args.n, v, p)
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) * 1000 / args.iters
+    tf = 4.74e6 * args.n / (us * 1e-6) / 1e12
+    print("fused net: n=%d  %.1f us/forward  %.1f TFLOP/s (%.1f%% of 2.5 PF fp16 dense)" % (args.n, us, tf, tf / 25.0))
+    ref = InferenceNet(sd, device="cuda", dtype=torch.float32)
+    planes = torch.from_numpy(board_planes(c0, c1)).cuda()
+    rv, rp = ref(planes)
+    print("max |dv| %.3g max |dp| %.3g" % ((v - rv).abs().max().item(), (p - rp).abs().max().item()))
+
+
+if __name__ == "__main__":
+    main()

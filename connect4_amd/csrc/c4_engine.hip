@@ -857,7 +857,7 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     d.rng_tape = cfg->rng_mode == C4_RNG_TAPE;
     d.stop_after_move = cfg->stop_after_move ? 1 : 0;
     d.max_inner = cfg->max_inner_iters > 0 ? cfg->max_inner_iters
-                                            : (cfg->eval_mode == C4_EVAL_CENTRE ? 1 << 20 : 8);
+                                            : (cfg->eval_mode == C4_EVAL_CENTRE ? 1 << 20 : 1);
     d.planes_dtype = cfg->planes_dtype;
     d.games_target = cfg->games_target;
     d.seed = cfg->seed;

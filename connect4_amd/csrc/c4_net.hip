@@ -6,12 +6,14 @@
 // value/policy MLPs in ONE kernel, writes values[n] in [0,1] and priors[n][7].
 //
 // Mapping (F = 32 filters):
-//   * one workgroup = 4 waves = 16 positions = 672 (position,pixel) rows = 21 MFMA tiles of 32 rows;
+//   * one workgroup = 8 waves (two per SIMD) = 16 positions = 672 (position,pixel) rows = 21 MFMA
+//     tiles of 32 rows;
 //   * every 3x3 conv is an implicit GEMM  out^T[cout][row] = sum_k W^T[cout][k] * act[k][row],
 //     k = (tap, cin), K = 288 = 18 steps of v_mfma_f32_32x32x16_f16 (A = weights, B = activations),
 //     so a lane's 16 accumulators are 16 couts of ONE pixel -> 4 packed 8-byte LDS stores;
 //   * weights of the current layer live in registers (18 x half8 = 72 VGPRs per lane, pre-swizzled
-//     on the host into MFMA lane order, one coalesced 1 KiB load per k-step);
+//     on the host into MFMA lane order); the next layer's 18 KiB are prefetched global -> registers
+//     -> LDS while the current layer computes, so no wave waits on L2 at a layer boundary;
 //   * activations ping-pong between two LDS buffers [672 rows][40 halves] (80-byte row stride makes
 //     the ds_read_b128 fragment reads bank-conflict free); zero padding is a per-row 9-bit tap
 //     mask, no halo; the residual add reads the skip element from the other buffer in the epilogue;
@@ -22,6 +24,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -40,7 +43,14 @@ constexpr int ROWS = P * PIX;         // 672
 constexpr int TILES = ROWS / 32;      // 21
 constexpr int CS = 40;                // halves per LDS row (32 channels + 8 pad => 80 B stride)
 constexpr int KSTEPS = 18;            // 9 taps x 32 cin / 16
-constexpr int NWAVES = 4;
+constexpr int NWAVES = 8;             // two waves per SIMD: one's LDS/epilogue hides under the other's MFMAs
+constexpr int NTHREADS = NWAVES * 64;
+constexpr int WCHUNKS = KSTEPS * 64;  // 16-byte A-fragment chunks per conv layer (18 KiB)
+constexpr int HEADV = 3 * PIX;        // 126 head activations per position
+constexpr int HSTR = 128;             // floats per position in the head scratch (16-byte aligned rows)
+constexpr int VT_F4 = 11 * 64;        // value table: [11 groups of 4 inputs][64 lanes] float4
+constexpr int PT_F = 11 * 64;         // policy table: [11][64] floats (lane = logit + 8*segment)
+constexpr int MLP_F4 = VT_F4 + PT_F / 4 + 3 * 16;   // + fc_b, vout_w, pfc_b (64 floats each) = 928 float4 = 14,848 B
 constexpr float LEAK = 0.01f;
 
 struct NetDev {
@@ -50,117 +60,246 @@ struct NetDev {
     const float *conv_b;   // [2R][32]
     const half8 *head_w;   // [2][64]           couts 0..2 = value, policy0, policy1
     const float *head_b;   // [4]
-    const float *vfc_w;    // [42][42] collapsed Linear stack
-    const float *vfc_b;    // [42]
-    const float *vout_w;   // [42]
-    const float *pfc_w;    // [7][84]
-    const float *pfc_b;    // [7]
+    const float4 *mlp;     // MLP_F4 float4s: value table [11][64][4], policy table [11][64], fc_b[64], vout_w[64], pfc_b[64]
     float vout_b, w1, w2;
     int n_res;
+    unsigned long long *stamps;   // diagnostic only (C4_NET_STAMPS=1): [wave][16] s_memtime values of block 0
 };
 
-__device__ __forceinline__ float lrelu(float v) { return v > 0.0f ? v : LEAK * v; }
+__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, LEAK * v); }   // slope < 1
 
-// epilogue of one 32-row tile: bias (+ skip) + LeakyReLU, fp16, 4 x 8-byte stores
-__device__ __forceinline__ void store_tile(const floatx16 &acc, const float *__restrict__ bias, _Float16 *dst,
-                                           const _Float16 *skip, int rowoff, int h)
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// epilogue of one 32-row tile.  Bias enters as the accumulator's initial value and the residual skip
+// as two extra MFMAs against an identity matrix, so what is left is LeakyReLU + fp16 + 4 stores.
+__device__ __forceinline__ void store_tile(const floatx16 &acc, _Float16 *dst, int rowoff, int h)
 {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int cb = 8 * q + 4 * h;
-        const float4 b4 = *reinterpret_cast<const float4 *>(bias + cb);
-        float v0 = acc[4 * q + 0] + b4.x, v1 = acc[4 * q + 1] + b4.y, v2 = acc[4 * q + 2] + b4.z,
-              v3 = acc[4 * q + 3] + b4.w;
-        if (skip) {
-            const half4 s4 = *reinterpret_cast<const half4 *>(skip + rowoff + cb);
-            v0 += (float)s4[0]; v1 += (float)s4[1]; v2 += (float)s4[2]; v3 += (float)s4[3];
-        }
         half4 o;
-        o[0] = (_Float16)lrelu(v0); o[1] = (_Float16)lrelu(v1); o[2] = (_Float16)lrelu(v2); o[3] = (_Float16)lrelu(v3);
-        *reinterpret_cast<half4 *>(dst + rowoff + cb) = o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (_Float16)lrelu(acc[4 * q + i]);
+        *reinterpret_cast<half4 *>(dst + rowoff + 8 * q + 4 * h) = o;
     }
 }
 
-__global__ __launch_bounds__(256) void c4_net_kernel(NetDev nd, const uint64_t *__restrict__ c0,
-                                                     const uint64_t *__restrict__ c1, int n,
-                                                     float *__restrict__ values, float *__restrict__ priors)
+__device__ __forceinline__ floatx16 acc_from_bias(const float4 (&b)[4])
 {
-    __shared__ __attribute__((aligned(16))) _Float16 lds[2][ROWS * CS];   // 2 x 53,760 B
+    floatx16 a;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a[4 * q] = b[q].x; a[4 * q + 1] = b[q].y; a[4 * q + 2] = b[q].z; a[4 * q + 3] = b[q].w; }
+    return a;
+}
+
+__global__ __launch_bounds__(NTHREADS) void c4_net_kernel(NetDev nd, const uint64_t *__restrict__ c0,
+                                                          const uint64_t *__restrict__ c1, int n,
+                                                          float *__restrict__ values, float *__restrict__ priors)
+{
+    // LDS: activations ping-pong 2 x 53,840 B (+ one all-zero row each that out-of-board taps read
+    // instead of branching) | conv weights double-buffered 2 x 18,432 B | MLP tables 14,848 B
+    // = 159,648 B of the CU's 160 KiB.
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2][(ROWS + 1) * CS];
+    __shared__ __attribute__((aligned(16))) half8 wbuf[2][WCHUNKS];
+    __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
+    __shared__ uint64_t sboard[2][P];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r32 = lane & 31, h = lane >> 5;
     const int pos0 = blockIdx.x * P;
+    const int n_layers = 2 * nd.n_res;
+
+    // conv weights of layer L+1 travel global -> registers -> LDS while layer L computes
+    half8 wpre[3];
+    auto prefetch = [&](int L) {
+        if (L < n_layers) {
+            const half8 *wsrc = nd.conv_w + (size_t)L * WCHUNKS;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = threadIdx.x + i * NTHREADS;
+                if (c < WCHUNKS) wpre[i] = wsrc[c];
+            }
+        }
+    };
+    auto commit = [&](int L) {
+        if (L < n_layers) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = threadIdx.x + i * NTHREADS;
+                if (c < WCHUNKS) wbuf[L & 1][c] = wpre[i];
+            }
+        }
+    };
+    auto stamp = [&](int i) {
+        if (nd.stamps && blockIdx.x == 0 && lane == 0) nd.stamps[wave * 16 + i] = __builtin_amdgcn_s_memtime();
+    };
+    // this lane's 16 output channels are {8q + 4h + 0..3 : q = 0..3}
+    auto load_bias = [&](const float *b, float4 (&out)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[q] = *reinterpret_cast<const float4 *>(b + 8 * q + 4 * h);
+    };
+    stamp(0);
+    prefetch(0);
+    if (threadIdx.x < 2 * P) {
+        const int which = threadIdx.x / P, p = threadIdx.x - which * P;
+        const int gp = pos0 + p;
+        sboard[which][p] = gp < n ? (which ? c1[gp] : c0[gp]) : 0;
+    } else if (threadIdx.x < 2 * P + 2 * CS) {   // zero rows
+        const int i = threadIdx.x - 2 * P;
+        lds[i / CS][ROWS * CS + i % CS] = (_Float16)0.0f;
+    }
+    {   // MLP tables: 928 float4, used only at the very end
+        const float4 m0 = nd.mlp[threadIdx.x];
+        const float4 m1 = threadIdx.x + NTHREADS < MLP_F4 ? nd.mlp[threadIdx.x + NTHREADS] : float4{0, 0, 0, 0};
+        mlp[threadIdx.x] = m0;
+        if (threadIdx.x + NTHREADS < MLP_F4) mlp[threadIdx.x + NTHREADS] = m1;
+    }
+    __syncthreads();
 
     // ------------------------------------------------------------------ stem: bitboards -> lds[0]
     {
         half8 w[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) w[s] = nd.stem_w[s * 64 + lane];
+        float4 bias[4];
+        load_bias(nd.stem_b, bias);
         for (int t = wave; t < TILES; t += NWAVES) {
             const int rg = t * 32 + r32;
             const int p = rg / PIX, pix = rg - p * PIX;
             const int y = pix / 7, x = pix - y * 7;
-            const int gp = pos0 + p;
-            const uint64_t b0 = gp < n ? c0[gp] : 0, b1 = gp < n ? c1[gp] : 0;
+            const uint64_t b0 = sboard[0][p], b1 = sboard[1][p];
             const float to_move = (__popcll(b0 | b1) & 1) ? 0.0f : 1.0f;   // board.py:150-152
-            floatx16 acc = {};
+            floatx16 acc = acc_from_bias(bias);
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
                 half8 bf;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = 16 * s + 8 * h + j;   // k = tap*4 + channel (channel 3 = zero pad)
-                    const int tap = k >> 2, ch = k & 3;
-                    float v = 0.0f;
-                    const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-                    if (tap < 9 && ch < 3 && yy >= 0 && yy < 6 && xx >= 0 && xx < 7) {
-                        const int bit = xx * 7 + (5 - yy);   // row 0 of the planes = top of the board
-                        v = ch == 0 ? to_move : (float)(((ch == 1 ? b0 : b1) >> bit) & 1);
-                    }
-                    bf[j] = (_Float16)v;
+                for (int jt = 0; jt < 2; ++jt) {
+                    // k = 16s + 8h + j = tap*4 + channel  =>  tap = 4s + 2h + jt, channel = j & 3 (3 = zero pad)
+                    const int tap = 4 * s + 2 * h + jt;
+                    const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;   // tap/3, tap%3 for tap < 12
+                    const int yy = y + ty - 1, xx = x + tx - 1;
+                    const bool ok = tap < 9 && (unsigned)yy < 6u && (unsigned)xx < 7u;
+                    const int bit = ok ? xx * 7 + (5 - yy) : 0;          // row 0 of the planes = top of the board
+                    bf[4 * jt + 0] = (_Float16)(ok ? to_move : 0.0f);
+                    bf[4 * jt + 1] = (_Float16)(ok ? (float)((b0 >> bit) & 1) : 0.0f);
+                    bf[4 * jt + 2] = (_Float16)(ok ? (float)((b1 >> bit) & 1) : 0.0f);
+                    bf[4 * jt + 3] = (_Float16)0.0f;
                 }
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s], bf, acc, 0, 0, 0);
             }
-            store_tile(acc, nd.stem_b, lds[0], nullptr, rg * CS, h);
+            store_tile(acc, lds[0], rg * CS, h);
         }
     }
+    stamp(1);
+    commit(0);
     __syncthreads();
+    stamp(2);
 
     // ------------------------------------------------------------------ residual tower
-    const int n_layers = 2 * nd.n_res;
+    // A wave owns tiles wave, wave+8, wave+16 (the last only for waves 0..4) in every layer, so the
+    // per-row LDS offsets of the 9 taps are computed once and kept in registers.
+    constexpr int TPW = (TILES + NWAVES - 1) / NWAVES;   // 3
+    int rsel[TPW][9], rbase[TPW];
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int rg = (wave + ti * NWAVES) * 32 + r32;
+        const int p = rg / PIX, pix = rg - p * PIX;
+        const int y = pix / 7, x = pix - y * 7;
+        rbase[ti] = rg * CS;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            // zero padding without branches: out-of-board taps read the all-zero row (index ROWS)
+            const int ok = -(int)((unsigned)(y + dy) < 6u && (unsigned)(x + dx) < 7u);   // all ones / zero
+            rsel[ti][tap] = (((rg + dy * 7 + dx) & ok) | (ROWS & ~ok)) * CS + 8 * h;
+        }
+    }
+    half8 idf[2];   // identity A fragments: skip[cout][row] = sum_k I[cout][k] * x[k][row]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) idf[s][j] = (_Float16)((16 * s + 8 * h + j) == r32 ? 1.0f : 0.0f);
+
     for (int L = 0; L < n_layers; ++L) {
         const _Float16 *src = lds[L & 1];
         _Float16 *dst = lds[(L & 1) ^ 1];
         const bool second = L & 1;   // conv2 of a block: add the block input (lives in dst) and overwrite it
         half8 w[KSTEPS];
-        const half8 *wp = nd.conv_w + (size_t)L * KSTEPS * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) w[s] = wp[s * 64];
-        const float *bias = nd.conv_b + L * F;
-        for (int t = wave; t < TILES; t += NWAVES) {
-            const int rg = t * 32 + r32;
-            const int p = rg / PIX, pix = rg - p * PIX;
-            const int y = pix / 7, x = pix - y * 7;
-            floatx16 acc = {};
+        for (int s = 0; s < KSTEPS; ++s) w[s] = wbuf[L & 1][s * 64 + lane];
+        float4 bias[4];
+        load_bias(nd.conv_b + L * F, bias);
+        prefetch(L + 1);
+        // Tile pipeline.  The epilogue of tile i-1 (VALU: LeakyReLU, fp16 convert, stores) is cut into
+        // 8 slices that are interleaved, in program order, between the MFMA pairs of tile i, so it
+        // issues in the gaps of the dependent chain instead of after it.
+        floatx16 pacc = {};
+        int prow = 0;
+        bool have_prev = false;
+        half4 pend;
+        auto epi_slice = [&](int sl) {   // accumulator elements 2sl, 2sl+1 of the previous tile
+            pend[2 * (sl & 1)] = (_Float16)lrelu(pacc[2 * sl]);
+            pend[2 * (sl & 1) + 1] = (_Float16)lrelu(pacc[2 * sl + 1]);
+            if (sl & 1) *reinterpret_cast<half4 *>(dst + prow + 8 * (sl >> 1) + 4 * h) = pend;
+        };
 #pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-                const int tap = s >> 1;
-                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-                const bool valid = (unsigned)(y + dy) < 6u && (unsigned)(x + dx) < 7u;
-                half8 bf = {};
-                if (valid) bf = *reinterpret_cast<const half8 *>(src + (rg + dy * 7 + dx) * CS + (s & 1) * 16 + 8 * h);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s], bf, acc, 0, 0, 0);
+        for (int ti = 0; ti < TPW; ++ti) {
+            if (wave + ti * NWAVES < TILES) {
+                half8 bf[KSTEPS], xs[2];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) bf[s] = *reinterpret_cast<const half8 *>(src + rsel[ti][s >> 1] + (s & 1) * 16);
+                if (second) {
+                    xs[0] = *reinterpret_cast<const half8 *>(dst + rbase[ti] + 8 * h);
+                    xs[1] = *reinterpret_cast<const half8 *>(dst + rbase[ti] + 16 + 8 * h);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                floatx16 acc = acc_from_bias(bias);
+#pragma unroll
+                for (int k = 0; k < KSTEPS / 2; ++k) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[2 * k], bf[2 * k], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[2 * k + 1], bf[2 * k + 1], acc, 0, 0, 0);
+                    if (2 * k + 4 < KSTEPS) {
+                        bf[2 * k + 4] = *reinterpret_cast<const half8 *>(src + rsel[ti][k + 2]);
+                        bf[2 * k + 5] = *reinterpret_cast<const half8 *>(src + rsel[ti][k + 2] + 16);
+                    }
+                    if (have_prev && k < 8) epi_slice(k);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (second) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[0], xs[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[1], xs[1], acc, 0, 0, 0);
+                }
+                pacc = acc;
+                prow = rbase[ti];
+                have_prev = true;
+                // the other weight buffer has been idle since the previous layer's barrier: park the
+                // prefetched weights there as soon as the first tile is done (frees 12 VGPRs)
+                if (ti == 0) commit(L + 1);
             }
-            store_tile(acc, bias, dst, second ? dst : nullptr, rg * CS, h);
         }
+        store_tile(pacc, dst, prow, h);   // the wave's last tile has no chain to hide under
+        if (L < 6) stamp(3 + L);
         __syncthreads();
     }
+    stamp(9);
     // tower output is in lds[0] (n_layers is even)
 
     // ------------------------------------------------------------------ 1x1 head convs (value + 2 policy channels)
-    float *hs = reinterpret_cast<float *>(lds[1]);   // [P][3][42] fp32
+    float *hs = reinterpret_cast<float *>(lds[1]);   // [P][HSTR] fp32: value plane 0..41, policy planes 42..125
     {
         const half8 w0 = nd.head_w[lane], w1 = nd.head_w[64 + lane];
+        const float hb0 = nd.head_b[0], hb1 = nd.head_b[1], hb2 = nd.head_b[2];
         for (int t = wave; t < TILES; t += NWAVES) {
             const int rg = t * 32 + r32;
             const int p = rg / PIX, pix = rg - p * PIX;
@@ -170,53 +309,69 @@ __global__ __launch_bounds__(256) void c4_net_kernel(NetDev nd, const uint64_t *
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, a0, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, a1, acc, 0, 0, 0);
             if (h == 0) {   // couts 0..3 sit in registers 0..3 of the lower half-wave
-                hs[(p * 3 + 0) * PIX + pix] = lrelu(acc[0] + nd.head_b[0]);
-                hs[(p * 3 + 1) * PIX + pix] = lrelu(acc[1] + nd.head_b[1]);
-                hs[(p * 3 + 2) * PIX + pix] = lrelu(acc[2] + nd.head_b[2]);
+                hs[p * HSTR + 0 * PIX + pix] = lrelu(acc[0] + hb0);
+                hs[p * HSTR + 1 * PIX + pix] = lrelu(acc[1] + hb1);
+                hs[p * HSTR + 2 * PIX + pix] = lrelu(acc[2] + hb2);
             }
         }
+        if (threadIdx.x < 2 * P) hs[(threadIdx.x >> 1) * HSTR + HEADV + (threadIdx.x & 1)] = 0.0f;   // pad 126,127
     }
     __syncthreads();
+    stamp(10);
 
-    // ------------------------------------------------------------------ MLP heads (fp32 VALU): 16 lanes per position
+    // ------------------------------------------------------------------ MLP heads (fp32 VALU)
+    // wave w owns positions 2w and 2w+1.
+    //  value : lane o < 42 is one row of the collapsed Linear stack (model.py:69-70,83): 11 float4
+    //          table reads + 11 broadcast float4 reads of the value plane per position;
+    //  policy: lane = logit + 8*segment, each lane sums 11 of the 84 inputs (model.py:104,113),
+    //          segments are combined with three xor-shuffles.
     {
-        const int p = threadIdx.x >> 4, j = threadIdx.x & 15;
-        const int gp = pos0 + p;
-        const float *hv = hs + p * 3 * PIX;   // value plane, 42
-        const float *hp = hv + PIX;           // policy planes, 84 (channel-major = view(N,1,-1) order)
-        float part = 0.0f;
+        const float *vt_b = reinterpret_cast<const float *>(mlp + VT_F4 + PT_F / 4);   // fc_b | vout_w | pfc_b
+        const float *pt = reinterpret_cast<const float *>(mlp + VT_F4);
+        const int pA = 2 * wave, pB = pA + 1;
+        const float4 *hA4 = reinterpret_cast<const float4 *>(hs + pA * HSTR);
+        const float4 *hB4 = reinterpret_cast<const float4 *>(hs + pB * HSTR);
+        float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
-        for (int oo = 0; oo < 3; ++oo) {
-            const int o = j + 16 * oo;
-            if (o < PIX) {
-                float a = nd.vfc_b[o];
-                const float *wr = nd.vfc_w + o * PIX;
-                for (int i = 0; i < PIX; ++i) a += wr[i] * hv[i];
-                part += nd.vout_w[o] * lrelu(a);   // model.py:83-85
+        for (int g = 0; g < 11; ++g) {
+            const float4 wv = mlp[g * 64 + lane];
+            const float4 xa = hA4[g], xb = hB4[g];
+            a0 += wv.x * xa.x + wv.y * xa.y + wv.z * xa.z + wv.w * xa.w;
+            a1 += wv.x * xb.x + wv.y * xb.y + wv.z * xb.z + wv.w * xb.w;
+        }
+        const int seg = lane >> 3;
+        const float *hpA = hs + pA * HSTR + PIX + seg * 11, *hpB = hs + pB * HSTR + PIX + seg * 11;
+        float l0 = 0.0f, l1 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 11; ++c) {
+            const float wv = pt[c * 64 + lane];      // zero where seg*11 + c >= 84 or (lane & 7) == 7
+            l0 += wv * hpA[c];
+            l1 += wv * hpB[c];
+        }
+#pragma unroll
+        for (int m = 8; m <= 32; m <<= 1) {
+            l0 += __shfl_xor(l0, m, 64);
+            l1 += __shfl_xor(l1, m, 64);
+        }
+        const float fb = vt_b[lane], vw = vt_b[64 + lane], pb = vt_b[128 + lane];
+        const bool is_pol = lane < 7;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const float a = (pp ? a1 : a0) + fb;
+            const float lg = (pp ? l1 : l0) + pb;
+            const int gp = pos0 + (pp ? pB : pA);
+            const float vsum = wave_sum(lane < PIX ? vw * lrelu(a) : 0.0f);          // model.py:83-85
+            const float value = (tanhf(vsum + nd.vout_b) + nd.w1) * nd.w2;           // model.py:86-88
+            const float mx = wave_max(is_pol ? lg : -INFINITY);
+            const float e = is_pol ? expf(lg - mx) : 0.0f;
+            const float sum = wave_sum(e);
+            if (gp < n) {
+                if (lane == 0) values[gp] = value;
+                if (is_pol) priors[(size_t)gp * 7 + lane] = e / sum;
             }
         }
-#pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) part += __shfl_xor(part, m, 16);
-        const float value = (tanhf(part + nd.vout_b) + nd.w1) * nd.w2;   // model.py:86-88
-        float logit = -INFINITY;
-        if (j < 7) {
-            float a = nd.pfc_b[j];
-            const float *wr = nd.pfc_w + j * 2 * PIX;
-            for (int i = 0; i < 2 * PIX; ++i) a += wr[i] * hp[i];
-            logit = a;
-        }
-        float mx = logit;
-#pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 16));
-        const float e = j < 7 ? expf(logit - mx) : 0.0f;
-        float sum = e;
-#pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 16);
-        if (gp < n) {
-            if (j == 0) values[gp] = value;
-            if (j < 7) priors[(size_t)gp * 7 + j] = e / sum;
-        }
     }
+    stamp(11);
 }
 
 thread_local char n_err[512] = "";
@@ -246,6 +401,14 @@ hipError_t upload(c4_net *net, const std::vector<T> &host, const T **dev)
 extern "C" {
 
 const char *c4_net_last_error(void) { return n_err; }
+
+/* diagnostic: copy the s_memtime stamps of block 0 (needs C4_NET_STAMPS=1 at create time) */
+int c4_net_debug_stamps(c4_net *net, unsigned long long *out /* [8][16] */)
+{
+    if (!net || !out || !net->d.stamps) return C4_ESTATE;
+    if (hipDeviceSynchronize() != hipSuccess) return C4_EDEVICE;
+    return hipMemcpy(out, net->d.stamps, 8 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? C4_OK : C4_EDEVICE;
+}
 
 int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
 {
@@ -292,9 +455,27 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
                 head[(s * 64 + l) * 8 + j] = (_Float16)(co < 3 ? desc->head_w[co * F + ci] : 0.0f);
             }
     std::vector<float> stem_b(desc->stem_b, desc->stem_b + F), conv_b(desc->conv_b, desc->conv_b + (size_t)2 * R * F),
-        head_b(4, 0.0f), vfc_w(desc->vfc_w, desc->vfc_w + 42 * 42), vfc_b(desc->vfc_b, desc->vfc_b + 42),
-        vout_w(desc->vout_w, desc->vout_w + 42), pfc_w(desc->pfc_w, desc->pfc_w + 7 * 84), pfc_b(desc->pfc_b, desc->pfc_b + 7);
+        head_b(4, 0.0f), mlp((size_t)MLP_F4 * 4, 0.0f);
     for (int i = 0; i < 3; ++i) head_b[i] = desc->head_b[i];
+    {
+        float *vt = mlp.data();                     // [11][64][4]: input 4g+c of value row `lane`
+        float *pt = vt + (size_t)VT_F4 * 4;         // [11][64]: input seg*11+c of logit lane&7, seg = lane>>3
+        float *fb = pt + PT_F, *vw = fb + 64, *pb = vw + 64;
+        for (int o = 0; o < PIX; ++o) {
+            for (int i = 0; i < PIX; ++i) vt[((i / 4) * 64 + o) * 4 + (i % 4)] = desc->vfc_w[o * PIX + i];
+            fb[o] = desc->vfc_b[o];
+            vw[o] = desc->vout_w[o];
+        }
+        for (int l = 0; l < 64; ++l) {
+            const int o = l & 7, seg = l >> 3;
+            if (o >= 7) continue;
+            for (int c = 0; c < 11; ++c) {
+                const int j = seg * 11 + c;
+                if (j < 2 * PIX) pt[c * 64 + l] = desc->pfc_w[o * 2 * PIX + j];
+            }
+            if (seg == 0) pb[l] = desc->pfc_b[o];
+        }
+    }
     if (conv.empty()) conv.resize(8);
     if (conv_b.empty()) conv_b.resize(4);
     hipError_t r = hipSuccess;
@@ -302,8 +483,12 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
 #define UP16(vec, field) if (r == hipSuccess) { r = upload(net, vec, &p16); net->d.field = (const half8 *)p16; }
 #define UP32(vec, field) if (r == hipSuccess) r = upload(net, vec, &net->d.field);
     UP16(stem, stem_w) UP16(conv, conv_w) UP16(head, head_w)
-    UP32(stem_b, stem_b) UP32(conv_b, conv_b) UP32(head_b, head_b) UP32(vfc_w, vfc_w) UP32(vfc_b, vfc_b)
-    UP32(vout_w, vout_w) UP32(pfc_w, pfc_w) UP32(pfc_b, pfc_b)
+    UP32(stem_b, stem_b) UP32(conv_b, conv_b) UP32(head_b, head_b)
+    {
+        const float *pm = nullptr;
+        if (r == hipSuccess) r = upload(net, mlp, &pm);
+        net->d.mlp = reinterpret_cast<const float4 *>(pm);
+    }
 #undef UP16
 #undef UP32
     if (r != hipSuccess) {
@@ -315,6 +500,14 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
     net->d.w1 = desc->w1;
     net->d.w2 = desc->w2;
     net->d.n_res = R;
+    if (getenv("C4_NET_STAMPS")) {
+        void *q = nullptr;
+        if (hipMalloc(&q, 8 * 16 * sizeof(unsigned long long)) == hipSuccess) {
+            (void)hipMemset(q, 0, 8 * 16 * sizeof(unsigned long long));
+            net->allocs.push_back(q);
+            net->d.stamps = (unsigned long long *)q;
+        }
+    }
     *out = net;
     return C4_OK;
 }
@@ -336,7 +529,7 @@ int c4_net_forward(c4_net *net, void *hip_stream, const uint64_t *color0_dev, co
         return C4_EINVAL;
     }
     if (n == 0) return C4_OK;
-    const dim3 grid((n + P - 1) / P), block(256);
+    const dim3 grid((n + P - 1) / P), block(NTHREADS);
     hipLaunchKernelGGL(c4_net_kernel, grid, block, 0, (hipStream_t)hip_stream, net->d, color0_dev, color1_dev, (int)n,
                        values_dev, priors_dev);
     hipError_t r = hipGetLastError();

@@ -221,6 +221,9 @@ int c4_net_destroy(c4_net *net);
 int c4_net_forward(c4_net *net, void *hip_stream, const uint64_t *color0_dev, const uint64_t *color1_dev,
                    int32_t n, float *values_dev, float *priors_dev);
 const char *c4_net_last_error(void);
+/* diagnostic build aid: per-phase s_memtime stamps of workgroup 0, [8 waves][16]; needs the
+ * environment variable C4_NET_STAMPS=1 when the net is created, else C4_ESTATE. */
+int c4_net_debug_stamps(c4_net *net, unsigned long long *out);
 
 int c4_abi_version(void);
 

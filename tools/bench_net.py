@@ -43,6 +43,16 @@ def main():
     planes = torch.from_numpy(board_planes(c0, c1)).cuda()
     rv, rp = ref(planes)
     print("max |dv| %.3g max |dp| %.3g" % ((v - rv).abs().max().item(), (p - rp).abs().max().item()))
+    if os.environ.get("C4_NET_STAMPS"):
+        import ctypes as C
+        out = (C.c_uint64 * 128)()
+        rc = net._lib.c4_net_debug_stamps(net._h, out)
+        st = np.array(list(out), dtype=np.int64).reshape(8, 16)
+        names = ["start", "stem", "bar0"] + ["L%d" % i for i in range(6)] + ["tower_end", "heads", "fc_end"]
+        for w in range(8):
+            d = st[w, 1:12] - st[w, 0:11]
+            print("wave %d: " % w + " ".join("%s=%d" % (n, x) for n, x in zip(names[1:], d)) + "  total=%d" % (st[w, 11] - st[w, 0]) +
+                  "  | tile(L2): addr=%d chain=%d epi=%d" % (st[w, 13] - st[w, 12], st[w, 14] - st[w, 13], st[w, 15] - st[w, 14]))
 
 
 if __name__ == "__main__":

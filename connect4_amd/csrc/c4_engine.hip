@@ -46,22 +46,48 @@ constexpr int SLOT_ACTIVE = 0;
 constexpr int SLOT_PARKED = 1;
 constexpr int SLOT_MOVE_DONE = 2;
 
-// info word: [0:21] child_base (slots) | [22:24] nchild | [25:27] status | [28:30] move | [31] prior is f64
+// info word: [0:18] child block (child_base/8) | [19:21] nchild | [22:24] status | [25:30] bit index of
+// the stone this move drops (col*7 + row, so the descent replays it with one shift/xor) | [31] prior is f64
 __host__ __device__ __forceinline__ uint32_t pack_info(uint32_t base, uint32_t nchild, uint32_t status,
-                                                       uint32_t move, uint32_t pf64)
+                                                       uint32_t bit, uint32_t pf64)
 {
-    return base | (nchild << 22) | (status << 25) | (move << 28) | (pf64 << 31);
+    return (base >> 3) | (nchild << 19) | (status << 22) | (bit << 25) | (pf64 << 31);
 }
-__host__ __device__ __forceinline__ uint32_t info_base(uint32_t i) { return i & 0x3fffffu; }
-__host__ __device__ __forceinline__ uint32_t info_nchild(uint32_t i) { return (i >> 22) & 7u; }
-__host__ __device__ __forceinline__ uint32_t info_status(uint32_t i) { return (i >> 25) & 7u; }
-__host__ __device__ __forceinline__ uint32_t info_move(uint32_t i) { return (i >> 28) & 7u; }
+__host__ __device__ __forceinline__ uint32_t info_base(uint32_t i) { return (i & 0x7ffffu) << 3; }
+__host__ __device__ __forceinline__ uint32_t info_nchild(uint32_t i) { return (i >> 19) & 7u; }
+__host__ __device__ __forceinline__ uint32_t info_status(uint32_t i) { return (i >> 22) & 7u; }
+__host__ __device__ __forceinline__ uint32_t info_bit(uint32_t i) { return (i >> 25) & 63u; }
+__host__ __device__ __forceinline__ uint32_t info_move(uint32_t i) { return info_bit(i) / 7u; }
 __host__ __device__ __forceinline__ uint32_t info_pf64(uint32_t i) { return i >> 31; }
 
 struct __attribute__((aligned(16))) PathEntry {
     uint32_t node;
     uint32_t n;   // visit count seen during the descent
     double w;     // value sum seen during the descent
+};
+
+constexpr int BLOCK_BYTES = 256;
+// One node = one 32-byte record; the (up to 7) children of a node are 8-aligned consecutive records,
+// i.e. one 256-byte sibling block = two 128-byte lines.  Lane k of a slot's 8-lane group reads child
+// k's whole record with two 16-byte loads, so the group's loads coalesce into exactly those two
+// lines.  (Measured on MI355X: per-field arrays cost 5 load instructions per level, each touching the
+// same lines again)
+struct __attribute__((aligned(32))) Rec {
+    double w;        // value sum          (SearchEvaluation.value_sum, mcts.py:49)
+    double q;        // w / n, refreshed by every backup (what tree.py:35 divides out on each read)
+    double p;        // prior of this node as seen from its parent
+    uint32_t n;      // visit count        (mcts.py:50)
+    uint32_t info;   // child_base | nchild | status | move | prior-is-f64
+};
+static_assert(sizeof(Rec) == 32, "node record must be 32 bytes");
+struct Pool {   // view of one slot's node pool; node id = block*8 + k
+    uint8_t *base;
+    __device__ __forceinline__ Rec *rec(uint32_t i) const { return reinterpret_cast<Rec *>(base) + i; }
+    __device__ __forceinline__ uint32_t &n(uint32_t i) const { return rec(i)->n; }
+    __device__ __forceinline__ uint32_t &info(uint32_t i) const { return rec(i)->info; }
+    __device__ __forceinline__ double &w(uint32_t i) const { return rec(i)->w; }
+    __device__ __forceinline__ double &q(uint32_t i) const { return rec(i)->q; }
+    __device__ __forceinline__ double &p(uint32_t i) const { return rec(i)->p; }
 };
 
 struct SlotStats {  // per-slot counters (summed on the host; no atomics => deterministic)
@@ -71,11 +97,8 @@ struct SlotStats {  // per-slot counters (summed on the host; no atomics => dete
 constexpr int N_STATS = sizeof(SlotStats) / sizeof(uint64_t);
 
 struct Dev {
-    // node pools (SoA)
-    uint32_t *N;
-    double *W;
-    double *P;
-    uint32_t *info;
+    // node pools: per slot `cap` records of 32 B (struct Rec), children in 8-aligned sibling blocks
+    uint8_t *pool;
     // slot state
     uint64_t *root_c0, *root_c1, *leaf_c0, *leaf_c1;
     int32_t *has_leaf;
@@ -95,8 +118,7 @@ struct Dev {
     double *res_value;
     double *res_policy;      // [G][7]
     // score tables, index = parent visit count
-    const double *tabA;      // log((n + base + 1)/base) + init   (mcts.py:150-152)
-    const double *tabB;      // sqrt(n)                           (mcts.py:156)
+    const double2 *tabAB;    // .x = log((n + base + 1)/base) + init (mcts.py:150-152), .y = sqrt(n) (mcts.py:156)
     // RNG tapes (C4_RNG_TAPE)
     const double *noise_tape;  // [tape_games][42][7]
     const double *u_tape;      // [tape_games][42]
@@ -124,6 +146,7 @@ struct Dev {
     long long games_target;
     double alpha, frac;
     uint64_t seed;
+    unsigned long long *stamps;   // diagnostic (C4_TREE_STAMPS=1): [block][8] s_memtime values, first 256 blocks
 };
 
 // ------------------------------------------------------------------------------------------
@@ -197,30 +220,30 @@ __device__ inline double rng_gamma(uint64_t seed, long long gid, uint32_t ply, u
     return boost * dd;
 }
 
-// tree.py:27-44 + utils.py:33-34: value of a child from `side`'s point of view.
-__device__ __forceinline__ double child_value_for(uint32_t status, uint32_t n, double w, int side)
+// tree.py:27-44 + utils.py:33-34: value of a child from `side`'s point of view (branch-free).
+__device__ __forceinline__ double child_value_for(uint32_t status, uint32_t n, double q, int side)
 {
-    double v;
-    if (status >= ST_XWIN) v = 0.5 * (double)(status - ST_XWIN);  // exact result, not the running mean
-    else if (n > 0) v = w / (double)n;
-    else return 0.0;                                               // unknown: assume lost
-    return side == 0 ? v : 1.0 - v;
+    const bool term = status >= ST_XWIN;
+    // terminal: exact result, not the running mean; visited: q = value_sum / visit_count (refreshed by
+    // every backup); unknown: 0.0 for either side ("assume lost")
+    const double v = term ? 0.5 * (double)(status - ST_XWIN) : q;
+    const double sv = side == 0 ? v : 1.0 - v;
+    return (term || n > 0) ? sv : 0.0;
 }
 
-// mcts.py:147-161 ucb_score.  A = log(..)+pb_c_init and B = sqrt(Np) come from the host tables.
+// mcts.py:147-161 ucb_score.  A = log(..)+pb_c_init and B = sqrt(Np) come from the host table.
 // pf64: the parent's prior is float64 (heuristic / table evaluator, or the root after Dirichlet
 // noise, mcts.py:180).  Otherwise it is a float32 net output and NumPy>=2 keeps
 // `pb_c * prior[c]` and `prior_score + value_score` in float32 (weak Python scalars, NEP 50).
+// Both forms are computed and one is selected: no divergent branch in the descent loop.
 __device__ __forceinline__ double ucb_score(double A, double B, uint32_t nc, double p, double V, uint32_t pf64)
 {
     const double pbc = A * (B / (double)(nc + 1));
-    if (pf64) {
-        const double prior_score = pbc * p;
-        return prior_score + V;
-    }
-    const float prior_score = (float)pbc * (float)p;
-    const float s = prior_score + (float)V;
-    return (double)s;
+    const double prior_score64 = pbc * p;
+    const double s64 = prior_score64 + V;
+    const float prior_score32 = (float)pbc * (float)p;
+    const float s32 = prior_score32 + (float)V;
+    return pf64 ? s64 : (double)s32;
 }
 
 // argmax over the group on (score, k); ties -> larger k == higher column (tree.py:11-15).
@@ -233,6 +256,49 @@ __device__ __forceinline__ int group_argmax(double s, int k)
         if (os > s || (os == s && ok > k)) { s = os; k = ok; }
     }
     return k;
+}
+
+// ---- DPP butterfly over an 8-lane group (no LDS crossbar: v_mov_dpp runs at VALU speed) --------
+// step 0: quad_perm [1,0,3,2] (lane^1), step 1: quad_perm [2,3,0,1] (lane^2), step 2: row_half_mirror
+// (lane i <-> 7-i inside each aligned 8-lane half row).  After the three steps every lane of the
+// group holds the same winner, because ties are broken by a total order on (score, k).
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint64_t r = ((uint64_t)dpp_u32<CTRL>((uint32_t)(b >> 32)) << 32) | dpp_u32<CTRL>((uint32_t)b);
+    return __longlong_as_double((long long)r);
+}
+struct Pick {      // a candidate child with its record riding along
+    double s;      // PUCT score
+    int k;         // child index in the block (ascending column => tie-break on k == on column)
+    uint32_t n, info;
+    double w;
+};
+template <int CTRL>
+__device__ __forceinline__ void pick_step(Pick &a)
+{
+    const double os = dpp_f64<CTRL>(a.s);
+    const int ok = (int)dpp_u32<CTRL>((uint32_t)a.k);
+    const uint32_t on = dpp_u32<CTRL>(a.n), oi = dpp_u32<CTRL>(a.info);
+    const double ow = dpp_f64<CTRL>(a.w);
+    const bool take = (os > a.s) | ((os == a.s) & (ok > a.k));   // ties -> higher column (tree.py:11-15)
+    a.s = take ? os : a.s;
+    a.k = take ? ok : a.k;
+    a.n = take ? on : a.n;
+    a.info = take ? oi : a.info;
+    a.w = take ? ow : a.w;
+}
+__device__ __forceinline__ void group_pick(Pick &a)
+{
+    pick_step<0xB1>(a);    // quad_perm [1,0,3,2]
+    pick_step<0x4E>(a);    // quad_perm [2,3,0,1]
+    pick_step<0x141>(a);   // row_half_mirror
 }
 
 template <typename T>
@@ -261,11 +327,7 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
     }
     constexpr bool SCORE_F32 = (EVAL == C4_EVAL_EXTERNAL_F32);
 
-    const size_t nb = (size_t)g * d.cap;
-    uint32_t *__restrict__ aN = d.N + nb;
-    double *__restrict__ aW = d.W + nb;
-    double *__restrict__ aP = d.P + nb;
-    uint32_t *__restrict__ aI = d.info + nb;
+    const Pool pool{d.pool + (size_t)g * d.cap * (BLOCK_BYTES / 8)};
     PathEntry *gpath = d.path + (size_t)g * MAX_DEPTH;
 
     // slot state (group-uniform registers)
@@ -299,6 +361,12 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
         apply_now = true;   // (C4_EVAL_CENTRE never leaves a leaf pending across launches)
     }
 
+    auto stamp = [&](int i) {
+        if (d.stamps && blockIdx.x < 256 && threadIdx.x == 0) d.stamps[blockIdx.x * 8 + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(1);
     int inner = 0;
     for (;;) {
         // ---------------------------------------------------------------- evaluate_node + expand + backup
@@ -351,23 +419,24 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
             if (legal) {
                 const uint32_t k = (uint32_t)__popc(mask & ((1 << lane) - 1));
                 uint64_t c0 = leaf0, c1 = leaf1;
+                const uint32_t bit = (uint32_t)(H1 * lane + col_count(occ, lane));
                 const uint32_t cst = make_move(c0, c1, lane);
                 const uint32_t idx = base + k;
-                aN[idx] = 0;
-                aW[idx] = 0.0;
-                aP[idx] = prn;
-                aI[idx] = pack_info(0, 0, cst, (uint32_t)lane, 0);
+                *pool.rec(idx) = Rec{0.0, 0.0, prn, 0u, pack_info(0, 0, cst, bit, 0)};
             }
             if (lane == 0) {   // mcts.py:132-134: position_value / search_value.add(value)
-                aN[pend] = 1;
-                aW[pend] = ev_value;
-                aI[pend] = pack_info(base, nchild, ST_EVALUATED, info_move(pinfo), pf64);
+                pool.n(pend) = 1;
+                pool.w(pend) = ev_value;
+                pool.q(pend) = ev_value;
+                pool.info(pend) = pack_info(base, nchild, ST_EVALUATED, info_bit(pinfo), pf64);
             }
             // mcts.py:164-168 backpropagate over the ancestors (values captured during the descent)
             for (uint32_t i = lane; i < pdepth; i += GROUP) {
                 const PathEntry e = (EVAL == C4_EVAL_CENTRE) ? s_path[gl][i] : gpath[i];
-                aN[e.node] = e.n + 1;
-                aW[e.node] = e.w + ev_value;
+                const double nw = e.w + ev_value;
+                pool.n(e.node) = e.n + 1;
+                pool.w(e.node) = nw;
+                pool.q(e.node) = nw / (double)(e.n + 1);
             }
             st.leaf_evals += 1;
             st.children += nchild;
@@ -375,6 +444,7 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
             (void)age;
             pend = -1;
             group_fence();
+            stamp(2);
         }
 
         // ---------------------------------------------------------------- new root (Tree(board), tree.py:62-64)
@@ -399,15 +469,15 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
 
         // ---------------------------------------------------------------- move choice (mcts.py:78-88)
         if (sims >= (uint32_t)d.S) {
-            const uint32_t rinfo = aI[0];
+            const uint32_t rinfo = pool.info(0);
             const uint32_t cb = info_base(rinfo), nc = info_nchild(rinfo);
             const bool act = lane < (int)nc;
-            const uint32_t cn = act ? aN[cb + lane] : 0;
-            const double cw = act ? aW[cb + lane] : 0.0;
-            const uint32_t ci = act ? aI[cb + lane] : 0;
+            const uint32_t cn = act ? pool.n(cb + lane) : 0;
+            const double cq = act ? pool.q(cb + lane) : 0.0;
+            const uint32_t ci = act ? pool.info(cb + lane) : 0;
             const int root_age = popc64(root0 | root1);
             const int side = root_age & 1;
-            const double V = act ? child_value_for(info_status(ci), cn, cw, side) : 0.0;
+            const double V = act ? child_value_for(info_status(ci), cn, cq, side) : 0.0;
             // tree.py:104-109 + :139-147 values policy
             double vs = 0.0;
 #pragma unroll
@@ -443,12 +513,12 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
             if (kb < 0) kb = group_argmax(act ? V : -1.0, act ? lane : -1);   // tree.py:69-73 best_move
             const uint32_t bi = gshfl(ci, kb);
             const uint32_t bn = gshfl(cn, kb);
-            const double bw = gshfl(cw, kb);
+            const double bq = gshfl(cq, kb);
             const int mv = (int)info_move(bi);
             const uint32_t bst = info_status(bi);
             double absv;   // child.data.absolute_value (mcts.py:88)
             if (bst >= ST_XWIN) absv = 0.5 * (double)(bst - ST_XWIN);
-            else if (bn > 0) absv = bw / (double)bn;
+            else if (bn > 0) absv = bq;
             else absv = __longlong_as_double(0x7ff8000000000000LL);
             // policy by column
             const int rmask = legal_mask(root0 | root1);
@@ -514,37 +584,60 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
 
         // ---------------------------------------------------------------- descent (mcts.py:108-116)
         uint32_t cur = 0;
-        uint32_t cinfo = aI[0];
-        uint32_t cN = aN[0];
-        double cW = aW[0];
+        uint32_t cinfo = pool.info(0);
+        uint32_t cN = pool.n(0);
+        double cW = pool.w(0);
         uint64_t b0 = root0, b1 = root1;
         int age = popc64(b0 | b1);
         uint32_t depth = 0;
         if (lane == 0) s_path[gl][0] = PathEntry{0u, cN, cW};
+        unsigned long long lvl_t0 = d.stamps ? __builtin_amdgcn_s_memtime() : 0, lvl_wait = 0, lvl_alu = 0, lvl_cnt = 0;
         while (info_status(cinfo) == ST_EVALUATED) {
             const uint32_t cb = info_base(cinfo), nc = info_nchild(cinfo), pf64 = info_pf64(cinfo);
             if (cN == 1) st.expansions += 1;   // first descent through an evaluated node == expand_node
             const bool act = lane < (int)nc;
             const uint32_t idx = cb + lane;
-            const uint32_t n = act ? aN[idx] : 0;
-            const double w = act ? aW[idx] : 0.0;
-            const double p = act ? aP[idx] : 0.0;
-            const uint32_t inf = act ? aI[idx] : 0;
-            const double A = d.tabA[cN], B = d.tabB[cN];
-            const double V = child_value_for(info_status(inf), n, w, age & 1);
+            Rec r = {};
+            if (act) r = *pool.rec(idx);                      // two 16-byte loads per lane
+            const uint32_t n = r.n, inf = r.info;
+            const double w = r.w, q = r.q, p = r.p;
+            const double2 ab = d.tabAB[cN];
+            const double A = ab.x, B = ab.y;
+            if (d.stamps) {   // diagnostic: cycles spent waiting for this level's loads
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+                lvl_wait += t1 - lvl_t0;
+                lvl_t0 = t1;
+            }
+            const double V = child_value_for(info_status(inf), n, q, age & 1);
             const double s = act ? ucb_score(A, B, n, p, V, pf64) : -std::numeric_limits<double>::infinity();
-            const int kb = group_argmax(s, act ? lane : -1);   // mcts.py:141-142
-            const uint32_t binf = gshfl(inf, kb);
-            cN = gshfl(n, kb);
-            cW = gshfl(w, kb);
-            cinfo = binf;
-            cur = cb + (uint32_t)kb;
-            make_move(b0, b1, (int)info_move(binf));
+            Pick best{s, act ? lane : -1, n, inf, w};
+            group_pick(best);                                   // mcts.py:141-142 max((score, child))
+            cN = best.n;
+            cW = best.w;
+            cinfo = best.info;
+            cur = cb + (uint32_t)best.k;
+            {   // board.py:160-163 replayed: xor the recorded stone into the mover's colour
+                const uint64_t stone = 1ULL << info_bit(cinfo);
+                b0 ^= (age & 1) ? 0ULL : stone;
+                b1 ^= (age & 1) ? stone : 0ULL;
+            }
             age += 1;
             depth += 1;
             if (lane == 0) s_path[gl][depth] = PathEntry{cur, cN, cW};
+            if (d.stamps) {
+                const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+                lvl_alu += t2 - lvl_t0;
+                lvl_t0 = t2;
+                lvl_cnt += 1;
+            }
+        }
+        if (d.stamps && blockIdx.x < 256 && threadIdx.x == 0) {
+            d.stamps[blockIdx.x * 8 + 7] = (lvl_wait << 32) | (lvl_alu & 0xffffffffu);
+            d.stamps[blockIdx.x * 8 + 6] = ((unsigned long long)lvl_cnt << 32) | depth;
         }
         st.depth_sum += depth;
+        stamp(3);
         const uint32_t lst = info_status(cinfo);
         if (lst >= ST_XWIN) {
             // mcts.py:125-128,134 + :164-168: terminal leaf, exact result, no evaluator
@@ -552,8 +645,10 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
             group_fence();   // s_path written by lane 0
             for (uint32_t i = lane; i <= depth; i += GROUP) {
                 const PathEntry e = s_path[gl][i];
-                aN[e.node] = e.n + 1;
-                aW[e.node] = e.w + value;
+                const double nw = e.w + value;
+                pool.n(e.node) = e.n + 1;
+                pool.w(e.node) = nw;
+                pool.q(e.node) = nw / (double)(e.n + 1);
             }
             sims += 1;
             st.sims += 1;
@@ -582,6 +677,7 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
     }
 
     // ---------------------------------------------------------------- emit leaf + persist slot state
+    stamp(4);
     if (has_leaf) {
         if (lane == 0) { d.leaf_c0[g] = leaf0; d.leaf_c1[g] = leaf1; }
         if (planes_out) {
@@ -613,6 +709,8 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
 #pragma unroll
         for (int i = 0; i < N_STATS; ++i) sp[i] += sv[i];
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(5);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -653,25 +751,25 @@ __global__ void c4_gather_roots_kernel(Dev d, c4_root_result *out)
     if (g >= d.G) return;
     c4_root_result r;
     memset(&r, 0, sizeof(r));
-    const size_t nb = (size_t)g * d.cap;
+    const Pool pool{d.pool + (size_t)g * d.cap * (BLOCK_BYTES / 8)};
     r.state = d.state[g];
     r.move = d.res_move[g];
     r.value = d.res_value[g];
     r.color0 = d.root_c0[g];
     r.color1 = d.root_c1[g];
-    const uint32_t rinfo = d.info[nb];
+    const uint32_t rinfo = pool.info(0);
     for (int i = 0; i < 7; ++i) { r.child_status[i] = -2; r.values_policy[i] = d.res_policy[(size_t)g * 7 + i]; }
     if (info_status(rinfo) == ST_EVALUATED) {
-        r.root_visits = d.N[nb];
-        r.root_value_sum = d.W[nb];
+        r.root_visits = pool.n(0);
+        r.root_value_sum = pool.w(0);
         const uint32_t cb = info_base(rinfo), nc = info_nchild(rinfo);
         for (uint32_t k = 0; k < nc; ++k) {
-            const uint32_t ci = d.info[nb + cb + k];
+            const uint32_t ci = pool.info(cb + k);
             const int m = (int)info_move(ci);
-            r.child_visits[m] = d.N[nb + cb + k];
-            r.child_value_sum[m] = d.W[nb + cb + k];
+            r.child_visits[m] = pool.n(cb + k);
+            r.child_value_sum[m] = pool.w(cb + k);
             r.child_status[m] = info_status(ci) >= ST_XWIN ? (int32_t)(info_status(ci) - ST_XWIN) : -1;
-            r.root_prior[m] = d.P[nb + cb + k];
+            r.root_prior[m] = pool.p(cb + k);
         }
     }
     const uint64_t *sp = d.stats + (size_t)g * N_STATS;
@@ -820,6 +918,14 @@ extern "C" {
 
 int c4_abi_version(void) { return C4_ABI_VERSION; }
 
+/* diagnostic: s_memtime stamps of the last launch, [256 blocks][8] (needs C4_TREE_STAMPS=1 at create) */
+int c4_debug_stamps(c4_engine *e, unsigned long long *out)
+{
+    if (!e || !out || !e->d.stamps) return C4_ESTATE;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return C4_EDEVICE;
+    return hipMemcpy(out, e->d.stamps, 256 * 8 * 8, hipMemcpyDeviceToHost) == hipSuccess ? C4_OK : C4_EDEVICE;
+}
+
 const char *c4_last_error(const c4_engine *e) { return e ? e->err : g_err; }
 
 int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
@@ -869,10 +975,7 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
         c4_engine_destroy(e);                               \
         return rc;                                          \
     }
-    ALLOC(d.N, G * cap);
-    ALLOC(d.W, G * cap);
-    ALLOC(d.P, G * cap);
-    ALLOC(d.info, G * cap);
+    ALLOC(d.pool, G * cap * (BLOCK_BYTES / 8));
     ALLOC(d.root_c0, G); ALLOC(d.root_c1, G); ALLOC(d.leaf_c0, G); ALLOC(d.leaf_c1, G);
     ALLOC(d.has_leaf, G); ALLOC(d.pending, G); ALLOC(d.pending_depth, G); ALLOC(d.pending_info, G);
     ALLOC(d.sims_done, G); ALLOC(d.n_alloc, G); ALLOC(d.state, G); ALLOC(d.need_root, G);
@@ -888,21 +991,22 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     // score tables (host libm so that log() is the very function Python's math.log calls)
     {
         const size_t nt = (size_t)cfg->simulations + 4;
-        std::vector<double> A(nt), B(nt);
+        std::vector<double2> AB(nt);
         for (size_t n = 0; n < nt; ++n) {
-            A[n] = std::log((double)((long long)n + cfg->pb_c_base + 1) / (double)cfg->pb_c_base) + cfg->pb_c_init;
-            B[n] = std::sqrt((double)n);
+            AB[n].x = std::log((double)((long long)n + cfg->pb_c_base + 1) / (double)cfg->pb_c_base) + cfg->pb_c_init;
+            AB[n].y = std::sqrt((double)n);
         }
-        double *tA, *tB;
-        ALLOC(tA, nt); ALLOC(tB, nt);
-        hipError_t r1 = hipMemcpy(tA, A.data(), nt * sizeof(double), hipMemcpyHostToDevice);
-        hipError_t r2 = hipMemcpy(tB, B.data(), nt * sizeof(double), hipMemcpyHostToDevice);
-        if (r1 != hipSuccess || r2 != hipSuccess) { set_err(g_err, "table upload failed"); c4_engine_destroy(e); return C4_EDEVICE; }
-        d.tabA = tA;
-        d.tabB = tB;
+        double2 *tAB;
+        ALLOC(tAB, nt);
+        if (hipMemcpy(tAB, AB.data(), nt * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess) { set_err(g_err, "table upload failed"); c4_engine_destroy(e); return C4_EDEVICE; }
+        d.tabAB = tAB;
     }
 #undef ALLOC
     e->drained_tag.assign(R, -1);
+    if (getenv("C4_TREE_STAMPS")) {
+        unsigned long long *q = nullptr;
+        if (dev_alloc(e, &q, 256 * 8) == C4_OK) { (void)hipMemset(q, 0, 256 * 8 * 8); d.stamps = q; }
+    }
     *out = e;
     rc = c4_reset(e, nullptr, nullptr, cfg->n_slots);
     if (rc) { strncpy(g_err, e->err, 511); c4_engine_destroy(e); *out = nullptr; return rc; }

@@ -225,6 +225,11 @@ const char *c4_net_last_error(void);
  * environment variable C4_NET_STAMPS=1 when the net is created, else C4_ESTATE. */
 int c4_net_debug_stamps(c4_net *net, unsigned long long *out);
 
+/* diagnostic build aid: per-phase s_memtime stamps of the last c4_step launch, [256 workgroups][8]
+ * (0 start, 1 slot state loaded, 2 apply done, 3 descent done, 4 before emit, 5 end, 6 depth);
+ * needs C4_TREE_STAMPS=1 in the environment when the engine is created, else C4_ESTATE. */
+int c4_debug_stamps(c4_engine *e, unsigned long long *out);
+
 int c4_abi_version(void);
 
 #ifdef __cplusplus

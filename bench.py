@@ -75,8 +75,9 @@ def cpu_baseline(state_dict, sims, seconds, n_games):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24000)
-    ap.add_argument("--warmup", type=int, default=2400)
+    ap.add_argument("--steps", type=int, default=48000)
+    ap.add_argument("--warmup", type=int, default=24000,
+                    help="default covers one full game length so games/sec is a steady-state rate")
     ap.add_argument("--slots", type=int, default=4096, help="parallel games per GPU")
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--net", default="fused", choices=["fused", "torch"],
@@ -177,13 +178,21 @@ def main():
             sp.steps_done += 1
         torch.cuda.synchronize()
         p1 = sp.stats()
-        tree_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev)
-        net_ms = sum(b.elapsed_time(c) for _, b, c in ev) / len(ev)
+        # an event pair around ONE short kernel also times the record/launch gap: calibrate it with
+        # empty pairs on the same stream and subtract (rocprofv3's kernel-trace average is the check)
+        cal = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(200)]
+        for a, b in cal:
+            a.record(stream)
+            b.record(stream)
+        torch.cuda.synchronize()
+        ev_overhead_ms = sorted(a.elapsed_time(b) for a, b in cal)[len(cal) // 2]
+        tree_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev) - ev_overhead_ms
+        net_ms = sum(b.elapsed_time(c) for _, b, c in ev) / len(ev) - ev_overhead_ms
         psims = p1["simulations"] - p0["simulations"]
         pdepth = (p1["depth_sum"] - p0["depth_sum"]) / max(1, psims)
         sims_per_launch = psims / len(ev)
         tree_bytes = tree_bytes_per_sim(pdepth) * sims_per_launch
-        prof = dict(tree_ms=tree_ms, net_ms=net_ms, sims_per_launch=sims_per_launch, mean_depth=pdepth,
+        prof = dict(tree_ms=tree_ms, net_ms=net_ms, ev_overhead_ms=ev_overhead_ms, sims_per_launch=sims_per_launch, mean_depth=pdepth,
                     tree_bytes_per_launch=tree_bytes)
 
     if rank == 0:
@@ -218,23 +227,38 @@ def main():
                 "dirichlet_alpha": 0.3, "exploration_fraction": 0.25, "num_sampling_moves": 6,
             },
         }
+        pmc = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+        except OSError:
+            pass
         if prof:
             ach = prof["tree_bytes_per_launch"] / (prof["tree_ms"] * 1e-3) / 1e9
-            out["roofline"] = {
+            out["roofline_tree"] = {
                 "kernel": "c4_step_kernel<EXTERNAL_F32> (tree walk: apply+backup, PUCT descent, expand, emit)",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                "frac": ach / HBM_PEAK_GBPS,
+                # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+                # command (profiles/r01_pmc_traffic.json, KB -> bytes, uncorrected: gfx950 may under-count
+                # reads by up to 2x, MI355X_MICROARCH.md section HBM); not collectable inside this process
+                "traffic": ((pmc["FETCH_SIZE_tree"] + pmc["WRITE_SIZE_tree"]) * 1024.0
+                            if args.slots == 4096 and args.sims == 800 and "FETCH_SIZE_tree" in pmc else None),
+                "event_overhead_ms_subtracted": prof["ev_overhead_ms"],
                 "avg_launch_ms": prof["tree_ms"], "sims_per_launch": prof["sims_per_launch"],
                 "mean_depth": prof["mean_depth"], "algorithmic_bytes_per_launch": prof["tree_bytes_per_launch"],
                 "note": "dependent-load (latency) bound pointer chase; bytes = (136*D+332) per simulation",
             }
             tf = NET_MFLOP_PER_POSITION * 1e6 * args.slots / (prof["net_ms"] * 1e-3) / 1e12
             peak = FP32_MATRIX_PEAK_TF if args.net_dtype == "f32" else BF16_MFMA_PEAK_TF
-            out["roofline_net"] = {
+            out["roofline"] = {   # the dominant kernel by time is the leaf-batch network
+                "share_of_step": prof["net_ms"] / (prof["net_ms"] + prof["tree_ms"]),
                 "kernel": ("c4_net_kernel (fused stem+tower+heads, v_mfma_f32_32x32x16_f16)" if args.net == "fused"
                            else "leaf-batch policy/value net forward (PyTorch-ROCm / MIOpen convs)"),
                 "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
-                "avg_forward_ms": prof["net_ms"], "traffic": None,
+                "avg_forward_ms": prof["net_ms"],
+                "traffic": ((pmc["FETCH_SIZE_net"] + pmc["WRITE_SIZE_net"]) * 1024.0
+                            if args.slots == 4096 and args.net == "fused" and "FETCH_SIZE_net" in pmc else None),
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, args.sims, args.cpu_seconds, 256)

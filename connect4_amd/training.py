@@ -1,0 +1,71 @@
+"""Train step with the reference's recipe (oinkoink/neural/pytorch/model.py:138-169,
+200-250): SGD(momentum 0.9, weight decay 1e-4) + MultiStepLR, loss = MSE(value) + BCE(policy), 5 epochs x
+batch 4096, checkpoint dict with the three state dicts.  Stock PyTorch-ROCm; not on the hot path."""
+import os
+
+import torch
+import torch.nn as nn
+from torch.optim.lr_scheduler import MultiStepLR
+
+from .net import NetConfig, PolicyValueNet
+
+
+class ModelConfig:
+    """oinkoink/neural/config.py:19-39"""
+
+    def __init__(self, net_config=None, weight_decay=1e-4, momentum=0.9, initial_lr=0.01,
+                 milestones=(100, 300, 600), gamma=0.1, batch_size=4096, n_training_epochs=5, use_gpu=True):
+        self.net_config = net_config or NetConfig()
+        self.weight_decay = weight_decay
+        self.momentum = momentum
+        self.initial_lr = initial_lr
+        self.milestones = list(milestones)
+        self.gamma = gamma
+        self.batch_size = batch_size
+        self.n_training_epochs = n_training_epochs
+        self.use_gpu = use_gpu
+
+
+class Trainer:
+    def __init__(self, config: ModelConfig = None, file_name: str = None):
+        self.config = config or ModelConfig()
+        self.net = PolicyValueNet(self.config.net_config)
+        self.device = torch.device("cuda:0" if self.config.use_gpu and torch.cuda.is_available() else "cpu")
+        self.net.to(self.device)
+        self.optimiser = torch.optim.SGD(self.net.parameters(), lr=self.config.initial_lr,
+                                         momentum=self.config.momentum, weight_decay=self.config.weight_decay)
+        self.scheduler = MultiStepLR(self.optimiser, milestones=self.config.milestones, gamma=self.config.gamma)
+        if file_name is not None:   # model.py:157-161
+            ckpt = torch.load(file_name, map_location=self.device, weights_only=True)
+            self.net.load_state_dict(ckpt["net_state_dict"])
+            self.optimiser.load_state_dict(ckpt["optimiser_state_dict"])
+            self.scheduler.load_state_dict(ckpt["scheduler_state_dict"])
+        self.value_loss = nn.MSELoss()
+        self.prior_loss = nn.BCELoss()
+        self.net.eval()
+
+    def train(self, boards, values, priors, generator=None):
+        """One generation: n_training_epochs passes over (boards F32[N,3,6,7], values F32[N], priors F32[N,7])."""
+        n = boards.shape[0]
+        self.net.train()
+        last = None
+        for _ in range(self.config.n_training_epochs):
+            perm = torch.randperm(n, generator=generator)
+            for i in range(0, n, self.config.batch_size):
+                idx = perm[i:i + self.config.batch_size]
+                b, v, p = boards[idx].to(self.device), values[idx].to(self.device), priors[idx].to(self.device)
+                self.optimiser.zero_grad()
+                xv, xp = self.net(b)
+                loss = self.value_loss(xv, v) + self.prior_loss(xp, p)   # model.py:221-225
+                loss.backward()
+                self.optimiser.step()
+                last = float(loss.detach())
+        self.scheduler.step()       # once per generation (model.py:239)
+        self.net.eval()
+        return last
+
+    def save(self, folder_path):    # model.py:242-250
+        os.makedirs(folder_path, exist_ok=True)
+        torch.save({"net_state_dict": self.net.state_dict(),
+                    "optimiser_state_dict": self.optimiser.state_dict(),
+                    "scheduler_state_dict": self.scheduler.state_dict()}, os.path.join(folder_path, "net.pth"))

@@ -123,3 +123,31 @@ def test_data_writer_matches_reference_native_to_pytorch():
         assert np.array_equal(boards.astype(np.uint8), npz[g["name"] + "__data_boards"])
         assert np.array_equal(values, npz[g["name"] + "__data_values"])
         assert np.array_equal(priors, npz[g["name"] + "__data_priors"])
+
+
+def test_match_lockstep_equals_sequential_oracle(oracle):
+    """Match over the 7 one-ply openings, both colours, two deterministic players of different
+    strength: every game's result equals a sequential replay with the oracle."""
+    from connect4_amd import evaluators
+    from connect4_amd.match import Match
+    from connect4_amd.mcts import MCTS, MCTSConfig
+    ev = evaluators.Evaluator(evaluators.evaluate_centre_with_prior)
+    p1, p2 = MCTS("strong", MCTSConfig(120), ev), MCTS("weak", MCTSConfig(12), ev)
+    m = Match(False, p1, p2, plies=1, switch=True)
+    assert m.n == 7 and len(m.games) == 14
+    out = m.play()
+    cfgs = {"strong": oracle.make_config(120), "weak": oracle.make_config(12)}
+    wins = draws = losses = 0
+    for i, (b0, po, px) in enumerate(Match(False, p1, p2, plies=1, switch=True).games):
+        b = oracle.Board.from_bits(*b0.to_int_tuple())
+        while b.result == -1:
+            who = po if b.age % 2 == 0 else px
+            _, mv, _ = oracle.search_and_pick(cfgs[who.name], b, oracle.CentreEvaluator())
+            b.make_move(mv)
+        r = 0.5 * b.result
+        if i >= 7:
+            r = 1.0 - r
+        wins += r == 1.0
+        draws += r == 0.5
+        losses += r == 0.0
+    assert (out["wins"], out["draws"], out["losses"]) == (wins, draws, losses)

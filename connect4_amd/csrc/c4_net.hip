@@ -68,6 +68,26 @@ struct NetDev {
 
 __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, LEAK * v); }   // slope < 1
 
+// DPP cross-lane moves (VALU speed; ds_bpermute-based __shfl costs an LDS round trip each)
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// sum / max over each aligned group of 8 lanes (quad_perm xor1, xor2, row_half_mirror)
+__device__ __forceinline__ float sum8(float v) { v += dppf<0xB1>(v); v += dppf<0x4E>(v); v += dppf<0x141>(v); return v; }
+__device__ __forceinline__ float max8(float v)
+{
+    v = fmaxf(v, dppf<0xB1>(v)); v = fmaxf(v, dppf<0x4E>(v)); v = fmaxf(v, dppf<0x141>(v));
+    return v;
+}
+// sum over each 16-lane row (+ row_mirror)
+__device__ __forceinline__ float sum16(float v) { v = sum8(v); v += dppf<0x140>(v); return v; }
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
@@ -112,7 +132,6 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_kernel(NetDev nd, const uint6
     __shared__ __attribute__((aligned(16))) _Float16 lds[2][(ROWS + 1) * CS];
     __shared__ __attribute__((aligned(16))) half8 wbuf[2][WCHUNKS];
     __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
-    __shared__ uint64_t sboard[2][P];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r32 = lane & 31, h = lane >> 5;
@@ -150,14 +169,25 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_kernel(NetDev nd, const uint6
     };
     stamp(0);
     prefetch(0);
-    if (threadIdx.x < 2 * P) {
-        const int which = threadIdx.x / P, p = threadIdx.x - which * P;
-        const int gp = pos0 + p;
-        sboard[which][p] = gp < n ? (which ? c1[gp] : c0[gp]) : 0;
-    } else if (threadIdx.x < 2 * P + 2 * CS) {   // zero rows
-        const int i = threadIdx.x - 2 * P;
-        lds[i / CS][ROWS * CS + i % CS] = (_Float16)0.0f;
+    // NN input planes (board.py:147-154) as 4 halves per (position,pixel) row: [to-move, o, x, 0];
+    // they live in lds[1], which the tower only starts writing after the stem is done
+    _Float16 *inp = lds[1];
+    for (int r = threadIdx.x; r <= ROWS; r += NTHREADS) {
+        half4 v = {};
+        if (r < ROWS) {
+            const int p = r / PIX, pix = r - p * PIX;
+            const int y = pix / 7, x = pix - y * 7;
+            const int gp = pos0 + p;
+            const uint64_t b0 = gp < n ? c0[gp] : 0, b1 = gp < n ? c1[gp] : 0;
+            const int bit = x * 7 + (5 - y);                       // row 0 of the planes = top of the board
+            v[0] = (_Float16)((__popcll(b0 | b1) & 1) ? 0.0f : 1.0f);   // board.py:150-152
+            v[1] = (_Float16)(float)((b0 >> bit) & 1);
+            v[2] = (_Float16)(float)((b1 >> bit) & 1);
+        }
+        *reinterpret_cast<half4 *>(inp + r * 4) = v;               // r == ROWS: the zero row of the planes
     }
+    if (threadIdx.x < CS) lds[0][ROWS * CS + threadIdx.x] = (_Float16)0.0f;                  // zero rows of the two
+    else if (threadIdx.x >= 64 && threadIdx.x < 64 + CS) lds[1][ROWS * CS + threadIdx.x - 64] = (_Float16)0.0f;   // activation buffers
     {   // MLP tables: 928 float4, used only at the very end
         const float4 m0 = nd.mlp[threadIdx.x];
         const float4 m1 = threadIdx.x + NTHREADS < MLP_F4 ? nd.mlp[threadIdx.x + NTHREADS] : float4{0, 0, 0, 0};
@@ -166,7 +196,9 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_kernel(NetDev nd, const uint6
     }
     __syncthreads();
 
-    // ------------------------------------------------------------------ stem: bitboards -> lds[0]
+    // ------------------------------------------------------------------ stem: planes -> lds[0]
+    // K = 9 taps x 4 channels (36, padded to 48 = 3 MFMA steps); a lane's 8 k's are 2 taps x 4 channels,
+    // i.e. two 8-byte reads of the plane rows (out-of-board taps read the zero row)
     {
         half8 w[3];
 #pragma unroll
@@ -177,25 +209,21 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_kernel(NetDev nd, const uint6
             const int rg = t * 32 + r32;
             const int p = rg / PIX, pix = rg - p * PIX;
             const int y = pix / 7, x = pix - y * 7;
-            const uint64_t b0 = sboard[0][p], b1 = sboard[1][p];
-            const float to_move = (__popcll(b0 | b1) & 1) ? 0.0f : 1.0f;   // board.py:150-152
+            half4 v[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int tap = 4 * (i >> 1) + 2 * h + (i & 1);      // k = 16s + 8h + j = tap*4 + channel
+                const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;   // tap/3, tap%3 for tap < 12
+                const int ok = -(int)(tap < 9 && (unsigned)(y + ty - 1) < 6u && (unsigned)(x + tx - 1) < 7u);
+                const int row = ((rg + (ty - 1) * 7 + tx - 1) & ok) | (ROWS & ~ok);
+                v[i] = *reinterpret_cast<const half4 *>(inp + row * 4);
+            }
             floatx16 acc = acc_from_bias(bias);
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
                 half8 bf;
 #pragma unroll
-                for (int jt = 0; jt < 2; ++jt) {
-                    // k = 16s + 8h + j = tap*4 + channel  =>  tap = 4s + 2h + jt, channel = j & 3 (3 = zero pad)
-                    const int tap = 4 * s + 2 * h + jt;
-                    const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;   // tap/3, tap%3 for tap < 12
-                    const int yy = y + ty - 1, xx = x + tx - 1;
-                    const bool ok = tap < 9 && (unsigned)yy < 6u && (unsigned)xx < 7u;
-                    const int bit = ok ? xx * 7 + (5 - yy) : 0;          // row 0 of the planes = top of the board
-                    bf[4 * jt + 0] = (_Float16)(ok ? to_move : 0.0f);
-                    bf[4 * jt + 1] = (_Float16)(ok ? (float)((b0 >> bit) & 1) : 0.0f);
-                    bf[4 * jt + 2] = (_Float16)(ok ? (float)((b1 >> bit) & 1) : 0.0f);
-                    bf[4 * jt + 3] = (_Float16)0.0f;
-                }
+                for (int j = 0; j < 4; ++j) { bf[j] = v[2 * s][j]; bf[4 + j] = v[2 * s + 1][j]; }
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s], bf, acc, 0, 0, 0);
             }
             store_tile(acc, lds[0], rg * CS, h);
@@ -348,8 +376,11 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_kernel(NetDev nd, const uint6
             l0 += wv * hpA[c];
             l1 += wv * hpB[c];
         }
+        // combine the 8 segments: lanes i and i^8 with a row rotate, the four 16-lane rows with two shuffles
+        l0 += dppf<0x128>(l0);
+        l1 += dppf<0x128>(l1);
 #pragma unroll
-        for (int m = 8; m <= 32; m <<= 1) {
+        for (int m = 16; m <= 32; m <<= 1) {
             l0 += __shfl_xor(l0, m, 64);
             l1 += __shfl_xor(l1, m, 64);
         }
@@ -360,11 +391,12 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_kernel(NetDev nd, const uint6
             const float a = (pp ? a1 : a0) + fb;
             const float lg = (pp ? l1 : l0) + pb;
             const int gp = pos0 + (pp ? pB : pA);
-            const float vsum = wave_sum(lane < PIX ? vw * lrelu(a) : 0.0f);          // model.py:83-85
+            const float rs = sum16(lane < PIX ? vw * lrelu(a) : 0.0f);               // model.py:83-85
+            const float vsum = readlane_f(rs, 0) + readlane_f(rs, 16) + readlane_f(rs, 32);
             const float value = (tanhf(vsum + nd.vout_b) + nd.w1) * nd.w2;           // model.py:86-88
-            const float mx = wave_max(is_pol ? lg : -INFINITY);
+            const float mx = max8(is_pol ? lg : -INFINITY);                          // lanes 0..7 hold the logits
             const float e = is_pol ? expf(lg - mx) : 0.0f;
-            const float sum = wave_sum(e);
+            const float sum = sum8(e);
             if (gp < n) {
                 if (lane == 0) values[gp] = value;
                 if (is_pol) priors[(size_t)gp * 7 + lane] = e / sum;

@@ -42,8 +42,8 @@ class Match:
             if not live:
                 break
             for player in (self._player_1, self._player_2):
-                todo = [boards[i] for i in live
-                        if (self.games[i][1] if boards[i].age % 2 == 0 else self.games[i][2]) is player]
+                todo = [boards[i] for i in live if boards[i].result is None and
+                        (self.games[i][1] if boards[i].age % 2 == 0 else self.games[i][2]) is player]
                 _moves(player, todo)
         results = np.array([b.result.value for b in boards], dtype="f")
         if self.switch:                       # flip the games where player_2 moved first (match.py:53-56)

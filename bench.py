@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--net-dtype", default=None, choices=["f32", "f16", "bf16"], help="torch net only (default f32)")
     ap.add_argument("--steps-per-graph", type=int, default=8)
     ap.add_argument("--max-inner", type=int, default=0, help="evaluator-free simulations a slot may run per launch (0 = engine default)")
+    ap.add_argument("--eval-cache", type=int, default=0, help="log2 entries of the evaluation cache (0 auto, -1 off)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=200, help="event-timed eager steps for the roofline")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -125,7 +126,8 @@ def main():
         net = InferenceNet(sd, device="cuda:%d" % local_rank, dtype=tdt)
     sp = SelfPlay(net, args.slots, MCTSConfig.self_play(args.sims), seed=rank, device=local_rank,
                   games_target=-1, record_capacity_games=2 * args.slots, planes_dtype=tdt,
-                  use_graph=not args.no_graph, steps_per_graph=args.steps_per_graph, max_inner_iters=args.max_inner)
+                  use_graph=not args.no_graph, steps_per_graph=args.steps_per_graph, max_inner_iters=args.max_inner,
+                  eval_cache_log2_entries=args.eval_cache)
 
     def barrier():
         if world > 1:
@@ -216,6 +218,7 @@ def main():
             "children_created_per_sec": children / elapsed,
             "moves_per_sec": moves / elapsed,
             "terminal_sim_fraction": term / max(1.0, sims),
+            "eval_cache_hit_rate": (delta["eval_cache_hits"] / max(1, delta["eval_cache_probes"])),
             "mean_leaf_depth": mean_depth,
             "config": {
                 "workload": "%d parallel self-play games per GPU, %d sims/move, random-init resnet "
@@ -223,7 +226,7 @@ def main():
                 "slots_per_gpu": args.slots, "simulations": args.sims, "net": "32f-3res-4fc",
                 "net_impl": args.net, "net_dtype": args.net_dtype, "tree_dtype": "u64 bitboards, u32 visits, f64 value sums/priors",
                 "parallelism": "games sharded over %d GPU(s), no collective in the rollout path" % world,
-                "max_inner_iters": args.max_inner, "hip_graph": (not args.no_graph), "steps_per_graph": args.steps_per_graph,
+                "max_inner_iters": args.max_inner, "eval_cache_log2_entries": args.eval_cache, "hip_graph": (not args.no_graph), "steps_per_graph": args.steps_per_graph,
                 "dirichlet_alpha": 0.3, "exploration_fraction": 0.25, "num_sampling_moves": 6,
             },
         }

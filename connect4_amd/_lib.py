@@ -33,13 +33,14 @@ class Config(C.Structure):
                 ("num_sampling_moves", C.c_int32), ("eval_mode", C.c_int32), ("rng_mode", C.c_int32),
                 ("seed", C.c_uint64), ("stop_after_move", C.c_int32), ("games_target", C.c_int64),
                 ("record_capacity_games", C.c_int32), ("max_inner_iters", C.c_int32),
-                ("planes_dtype", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("planes_dtype", C.c_int32), ("eval_cache_log2_entries", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "simulations", "expansions", "children_created", "terminal_sims", "leaf_evals", "depth_sum",
-        "moves", "games_started", "games_finished", "launches", "active_slots", "capped_slots")]
+        "moves", "games_started", "games_finished", "launches", "active_slots", "capped_slots",
+        "eval_cache_hits", "eval_cache_probes")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -77,6 +78,7 @@ SIGNATURES = {
     "c4_engine_destroy": (C.c_int, [C.c_void_p]),
     "c4_last_error": (C.c_char_p, [C.c_void_p]),
     "c4_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "c4_clear_eval_cache": (C.c_int, [C.c_void_p]),
     "c4_reset": (C.c_int, [C.c_void_p, _u64p, _u64p, C.c_int32]),
     "c4_set_tapes": (C.c_int, [C.c_void_p, _f64p, _f64p, C.c_int32]),
     "c4_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

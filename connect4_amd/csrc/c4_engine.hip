@@ -90,9 +90,20 @@ struct Pool {   // view of one slot's node pool; node id = block*8 + k
     __device__ __forceinline__ double &p(uint32_t i) const { return rec(i)->p; }
 };
 
+// Evaluation cache entry: what the evaluator answered for one position (evaluators.py:18-25 keeps the
+// same thing in a dict keyed by (color0, color1)).  `check` ties key and payload together so that an
+// entry torn by two concurrent writers is rejected instead of believed.
+struct CacheEntry {
+    uint64_t key;      // color0 + (color0 | color1): unique for gravity-consistent positions (0xFF..F = empty)
+    uint64_t check;
+    float value;
+    float prior[7];
+};
+static_assert(sizeof(CacheEntry) == 48, "cache entry must be 48 bytes");
+
 struct SlotStats {  // per-slot counters (summed on the host; no atomics => deterministic)
     uint64_t sims, expansions, children, terminal_sims, leaf_evals, depth_sum, moves, games_started,
-        games_finished, capped;
+        games_finished, capped, cache_hits, cache_probes;
 };
 constexpr int N_STATS = sizeof(SlotStats) / sizeof(uint64_t);
 
@@ -146,6 +157,8 @@ struct Dev {
     long long games_target;
     double alpha, frac;
     uint64_t seed;
+    CacheEntry *cache;     // evaluation cache (evaluators.py:18-25 memo table), direct mapped; null = off
+    int cache_bits;
     unsigned long long *stamps;   // diagnostic (C4_TREE_STAMPS=1): [block][8] s_memtime values, first 256 blocks
 };
 
@@ -301,6 +314,50 @@ __device__ __forceinline__ void group_pick(Pick &a)
     pick_step<0x141>(a);   // row_half_mirror
 }
 
+// ---- evaluation cache ------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27; x *= 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ uint64_t group_xor64(uint64_t v)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo ^= dpp_u32<0xB1>(lo); hi ^= dpp_u32<0xB1>(hi);
+    lo ^= dpp_u32<0x4E>(lo); hi ^= dpp_u32<0x4E>(hi);
+    lo ^= dpp_u32<0x141>(lo); hi ^= dpp_u32<0x141>(hi);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t cache_key(uint64_t c0, uint64_t c1) { return c0 + (c0 | c1); }
+__device__ __forceinline__ CacheEntry *cache_slot(const Dev &d, uint64_t key)
+{
+    return d.cache + ((key * 0x9E3779B97F4A7C15ULL) >> (64 - d.cache_bits));
+}
+// check word over (key, value, prior[7]); lane k < 7 contributes prior[k], lane 7 the value
+__device__ __forceinline__ uint64_t cache_check(uint64_t key, float value, float prior_lane, int lane)
+{
+    const uint32_t bits = lane < 7 ? __float_as_uint(prior_lane) : __float_as_uint(value);
+    return key ^ group_xor64(mix64(((uint64_t)(lane + 1) << 32) | bits));
+}
+__device__ __forceinline__ bool cache_probe(const Dev &d, uint64_t c0, uint64_t c1, int lane, float &value, float &prior_lane)
+{
+    const uint64_t key = cache_key(c0, c1);
+    const CacheEntry *e = cache_slot(d, key);
+    const uint64_t k = e->key, chk = e->check;
+    value = e->value;
+    prior_lane = lane < 7 ? e->prior[lane] : 0.0f;
+    return k == key && chk == cache_check(key, value, prior_lane, lane);
+}
+__device__ __forceinline__ void cache_insert(const Dev &d, uint64_t c0, uint64_t c1, int lane, float value, float prior_lane)
+{
+    const uint64_t key = cache_key(c0, c1);
+    CacheEntry *e = cache_slot(d, key);
+    const uint64_t chk = cache_check(key, value, prior_lane, lane);
+    if (lane < 7) e->prior[lane] = prior_lane;
+    if (lane == 0) { e->value = value; e->check = chk; e->key = key; }
+}
+
 template <typename T>
 __device__ __forceinline__ void store_plane(void *planes, size_t idx, float v);
 template <> __device__ __forceinline__ void store_plane<float>(void *p, size_t i, float v) { ((float *)p)[i] = v; }
@@ -348,6 +405,8 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
     uint64_t leaf0 = 0, leaf1 = 0;
     double ev_value = 0.0, ev_prior = 0.0;   // ev_prior: lane k holds prior[k]
     bool apply_now = false;
+    bool path_lds = (EVAL == C4_EVAL_CENTRE);   // where the pending leaf's descent path lives
+    bool fresh_eval = false;                    // the answer came from the evaluator: remember it
     if (pend >= 0) {
         leaf0 = d.leaf_c0[g];
         leaf1 = d.leaf_c1[g];
@@ -359,6 +418,7 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
             ev_prior = lane < 7 ? ((const double *)priors_in)[(size_t)g * 7 + lane] : 0.0;
         }
         apply_now = true;   // (C4_EVAL_CENTRE never leaves a leaf pending across launches)
+        fresh_eval = (EVAL == C4_EVAL_EXTERNAL_F32) && d.cache != nullptr;
     }
 
     auto stamp = [&](int i) {
@@ -372,6 +432,10 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
         // ---------------------------------------------------------------- evaluate_node + expand + backup
         if (apply_now) {
             apply_now = false;
+            if (fresh_eval) {   // evaluators.py:21-24: position_table[key] = evaluate_fn(board)
+                fresh_eval = false;
+                cache_insert(d, leaf0, leaf1, lane, (float)ev_value, (float)ev_prior);
+            }
             const uint64_t occ = leaf0 | leaf1;
             const int age = popc64(occ);
             const int mask = legal_mask(occ);                    // tree.py:23 valid_moves (leaf is undecided)
@@ -432,7 +496,7 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
             }
             // mcts.py:164-168 backpropagate over the ancestors (values captured during the descent)
             for (uint32_t i = lane; i < pdepth; i += GROUP) {
-                const PathEntry e = (EVAL == C4_EVAL_CENTRE) ? s_path[gl][i] : gpath[i];
+                const PathEntry e = path_lds ? s_path[gl][i] : gpath[i];
                 const double nw = e.w + ev_value;
                 pool.n(e.node) = e.n + 1;
                 pool.w(e.node) = nw;
@@ -462,6 +526,17 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
                 ev_prior = 1.0 / 7.0;
                 apply_now = true;
                 continue;
+            }
+            if (EVAL == C4_EVAL_EXTERNAL_F32 && d.cache) {   // evaluators.py:19-20 position_table.get
+                float cv, cp;
+                st.cache_probes += 1;
+                if (cache_probe(d, leaf0, leaf1, lane, cv, cp)) {
+                    st.cache_hits += 1;
+                    ev_value = (double)cv;
+                    ev_prior = (double)cp;
+                    apply_now = true;
+                    continue;
+                }
             }
             has_leaf = 1;
             break;
@@ -671,6 +746,18 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
             continue;
         }
         group_fence();
+        if (EVAL == C4_EVAL_EXTERNAL_F32 && d.cache) {   // evaluators.py:19-20 position_table.get
+            float cv, cp;
+            st.cache_probes += 1;
+            if (cache_probe(d, b0, b1, lane, cv, cp)) {   // a hit is applied in place, like a terminal leaf
+                st.cache_hits += 1;
+                ev_value = (double)cv;
+                ev_prior = (double)cp;
+                path_lds = true;
+                apply_now = true;
+                continue;
+            }
+        }
         for (uint32_t i = lane; i < depth; i += GROUP) gpath[i] = s_path[gl][i];
         has_leaf = 1;
         break;
@@ -1003,6 +1090,22 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     }
 #undef ALLOC
     e->drained_tag.assign(R, -1);
+    {   // evaluation cache: <0 off, 0 auto (self-play with a float32 evaluator only), else log2(entries)
+        int bits = cfg->eval_cache_log2_entries;
+        if (bits == 0 && cfg->eval_mode == C4_EVAL_EXTERNAL_F32 && !cfg->stop_after_move) {
+            const uint64_t want = 4ULL * (uint64_t)cfg->n_slots * ((uint64_t)cfg->simulations + 1);
+            bits = 16;
+            while (bits < 26 && (1ULL << bits) < want) ++bits;
+        }
+        if (bits > 0 && cfg->eval_mode == C4_EVAL_EXTERNAL_F32) {
+            if (bits < 8 || bits > 30) { set_err(g_err, "eval_cache_log2_entries=%d out of range [8,30]", bits); c4_engine_destroy(e); *out = nullptr; return C4_EINVAL; }
+            CacheEntry *c = nullptr;
+            if (dev_alloc(e, &c, (size_t)1 << bits) != C4_OK) { strncpy(g_err, e->err, 511); c4_engine_destroy(e); *out = nullptr; return C4_ENOMEM; }
+            if (hipMemset(c, 0xFF, sizeof(CacheEntry) << bits) != hipSuccess) { set_err(g_err, "cache memset failed"); c4_engine_destroy(e); *out = nullptr; return C4_EDEVICE; }
+            d.cache = c;
+            d.cache_bits = bits;
+        }
+    }
     if (getenv("C4_TREE_STAMPS")) {
         unsigned long long *q = nullptr;
         if (dev_alloc(e, &q, 256 * 8) == C4_OK) { (void)hipMemset(q, 0, 256 * 8 * 8); d.stamps = q; }
@@ -1022,6 +1125,16 @@ int c4_engine_destroy(c4_engine *e)
     if (e->tape_noise) (void)hipFree(e->tape_noise);
     if (e->tape_u) (void)hipFree(e->tape_u);
     delete e;
+    return C4_OK;
+}
+
+int c4_clear_eval_cache(c4_engine *e)
+{
+    if (!e) return C4_EINVAL;
+    if (!e->d.cache) return C4_OK;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemset(e->d.cache, 0xFF, sizeof(CacheEntry) << e->d.cache_bits));
     return C4_OK;
 }
 
@@ -1128,6 +1241,8 @@ int c4_get_stats(c4_engine *e, c4_stats *out)
     out->games_started = (int64_t)t.games_started;
     out->games_finished = (int64_t)t.games_finished;
     out->capped_slots = (int64_t)t.capped;
+    out->eval_cache_hits = (int64_t)t.cache_hits;
+    out->eval_cache_probes = (int64_t)t.cache_probes;
     out->launches = e->launches;
     for (size_t g = 0; g < G; ++g) out->active_slots += stt[g] == SLOT_ACTIVE;
     return C4_OK;

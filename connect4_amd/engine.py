@@ -25,7 +25,7 @@ class Engine:
                  root_dirichlet_alpha=0.0, root_exploration_fraction=0.0, num_sampling_moves=0,
                  eval_mode=L.EVAL_EXTERNAL_F32, rng_mode=L.RNG_PHILOX, seed=0, stop_after_move=False,
                  games_target=-1, record_capacity_games=0, max_inner_iters=0,
-                 planes_dtype=L.PLANES_F32, device=0):
+                 planes_dtype=L.PLANES_F32, eval_cache_log2_entries=0, device=0):
         self._lib = L.load()
         self.cfg = L.Config()
         self.cfg.abi_version = L.ABI_VERSION
@@ -44,6 +44,7 @@ class Engine:
         self.cfg.record_capacity_games = int(record_capacity_games)
         self.cfg.max_inner_iters = int(max_inner_iters)
         self.cfg.planes_dtype = int(planes_dtype)
+        self.cfg.eval_cache_log2_entries = int(eval_cache_log2_entries)
         self.n_slots = int(n_slots)
         self.device = int(device)
         self._h = C.c_void_p()
@@ -69,6 +70,9 @@ class Engine:
 
     def _check(self, rc):
         L.check(rc, self._h)
+
+    def clear_eval_cache(self):
+        self._check(self._lib.c4_clear_eval_cache(self._h))
 
     def set_stream(self, stream_handle):
         self._check(self._lib.c4_set_stream(self._h, C.c_void_p(int(stream_handle))))

@@ -25,7 +25,8 @@ class SelfPlay:
 
     def __init__(self, net: Callable, n_slots: int, config: MCTSConfig, seed: int = 0, device: int = 0,
                  games_target: int = -1, record_capacity_games: int = 0, planes_dtype=torch.float32,
-                 use_graph: bool = True, steps_per_graph: int = 8, max_inner_iters: int = 0):
+                 use_graph: bool = True, steps_per_graph: int = 8, max_inner_iters: int = 0,
+                 eval_cache_log2_entries: int = 0):
         self.net = net
         self.n_slots = n_slots
         self.config = config
@@ -33,7 +34,8 @@ class SelfPlay:
         self.engine = Engine(n_slots, eval_mode=L.EVAL_EXTERNAL_F32, rng_mode=L.RNG_PHILOX, seed=seed,
                              stop_after_move=False, games_target=games_target,
                              record_capacity_games=record_capacity_games, max_inner_iters=max_inner_iters,
-                             planes_dtype=_PLANES[planes_dtype], device=device, **config.engine_kwargs())
+                             planes_dtype=_PLANES[planes_dtype], eval_cache_log2_entries=eval_cache_log2_entries,
+                             device=device, **config.engine_kwargs())
         with torch.cuda.device(self.device):
             self.values = torch.zeros(n_slots, dtype=torch.float32, device=self.device)
             self.priors = torch.full((n_slots, 7), 1.0 / 7.0, dtype=torch.float32, device=self.device)

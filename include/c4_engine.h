@@ -81,7 +81,13 @@ typedef struct {
                                           without needing the evaluator (terminal leaves); bounds
                                           launch time.  0 = default */
     int32_t planes_dtype;              /* C4_PLANES_* layout of the leaf batch handed to the net */
-    int32_t reserved[7];
+    int32_t eval_cache_log2_entries;   /* device-wide evaluation cache = the reference's memo table
+                                          (evaluators.py:9-25), shared by every slot and game: a leaf
+                                          whose position was already answered is applied in place, no
+                                          evaluator round trip.  Results are unchanged for a
+                                          deterministic evaluator.  <0 off, 0 auto (on for self-play
+                                          with C4_EVAL_EXTERNAL_F32), else log2 of the table size */
+    int32_t reserved[6];
 } c4_config;
 
 typedef struct c4_engine c4_engine;
@@ -100,6 +106,8 @@ typedef struct {
     int64_t launches;           /* rollout-step kernel launches */
     int64_t active_slots;       /* slots not parked right now */
     int64_t capped_slots;       /* slot-launches that hit max_inner_iters */
+    int64_t eval_cache_hits;    /* leaves answered by the evaluation cache (subset of leaf_evals) */
+    int64_t eval_cache_probes;
 } c4_stats;
 
 /* Root read-out of one slot (tree.py:66-117; what MCTS.make_move returns, mcts.py:88). */
@@ -138,6 +146,9 @@ int c4_engine_destroy(c4_engine *e);
 const char *c4_last_error(const c4_engine *e /* may be NULL */);
 /* Order the engine's kernels with the caller's stream (torch.cuda.current_stream().cuda_stream). */
 int c4_set_stream(c4_engine *e, void *hip_stream);
+/* Forget all cached evaluations (call when the evaluator's weights change; evaluators.py: a new
+ * Evaluator / position_table per generation, game_pool.py:21-27). */
+int c4_clear_eval_cache(c4_engine *e);
 
 /* Start positions for the first n_active slots (Tree(board), tree.py:62-64); NULL => empty boards
  * (Board(), board.py:36-41).  Remaining slots park.  Clears counters, records and game ids. */

@@ -156,15 +156,16 @@ def test_search_centre_vs_oracle_many(oracle):
     assert st["moves"] == len(boards)
 
 
-def check_selfplay(case, eval_mode, fn=None):
+def check_selfplay(case, eval_mode, fn=None, **engine_kw):
     from connect4_amd import _lib as L
     n = len(case["moves"])
     nz = np.zeros((1, 42, 7))
     nz[0, :n] = np.array(case["noise_tape"])
     u = np.full((1, 42), -1.0)
     u[0, :len(case["uniforms"])] = case["uniforms"]
+    engine_kw.setdefault("eval_cache_log2_entries", -1)
     with make_engine(case["config"], 1, eval_mode, rng_tape=True, games_target=1,
-                     record_capacity_games=4) as eng:
+                     record_capacity_games=4, **engine_kw) as eng:
         eng.set_tapes(nz, u)
         eng.reset()
         if eval_mode == L.EVAL_CENTRE:
@@ -184,6 +185,7 @@ def check_selfplay(case, eval_mode, fn=None):
         assert list(g.policy[i]) == case["policies"][i]
     assert st["games_finished"] == 1 and st["moves"] == n
     assert st["simulations"] == n * case["config"]["simulations"]
+    return st
 
 
 def test_selfplay_centre_golden():
@@ -200,3 +202,22 @@ def test_selfplay_net_table_golden():
     for case in load_json("selfplay_net.json"):
         fn = table_lookup_fn(*table_from_npz(npz, case["name"]))
         check_selfplay(case, L.EVAL_EXTERNAL_F32, fn)
+
+
+def test_eval_cache_is_transparent():
+    """The device evaluation cache (the reference's Evaluator memo table, evaluators.py:18-25) must not
+    change a single visit count: whole self-play games with the cache on (and several cached leaves
+    applied per launch) equal the golden games; the new root of every move after the first is a hit."""
+    from connect4_amd import _lib as L
+    npz = load_npz("selfplay_net_tables.npz")
+    for case in load_json("selfplay_net.json"):
+        seen = []
+        table = table_lookup_fn(*table_from_npz(npz, case["name"]))
+
+        def fn(c0, c1):
+            seen.append((int(c0), int(c1)))
+            return table(c0, c1)
+        st = check_selfplay(case, L.EVAL_EXTERNAL_F32, fn, eval_cache_log2_entries=16, max_inner_iters=4)
+        assert st["eval_cache_hits"] > 0.2 * st["leaf_evals"]
+        assert st["eval_cache_hits"] + len(seen) == st["leaf_evals"]
+        assert len(seen) - len(set(seen)) <= 0.02 * len(seen)   # re-evaluations only after direct-mapped evictions

@@ -84,8 +84,11 @@ def main():
                     help="fused: hand-written gfx950 MFMA kernel (fp16 storage, fp32 accumulate); torch: PyTorch-ROCm/MIOpen")
     ap.add_argument("--net-dtype", default=None, choices=["f32", "f16", "bf16"], help="torch net only (default f32)")
     ap.add_argument("--steps-per-graph", type=int, default=8)
-    ap.add_argument("--max-inner", type=int, default=0, help="evaluator-free simulations a slot may run per launch (0 = engine default)")
+    ap.add_argument("--max-inner", type=int, default=4, help="evaluator-free simulations a slot may run per launch (0 = engine default)")
     ap.add_argument("--eval-cache", type=int, default=0, help="log2 entries of the evaluation cache (0 auto, -1 off)")
+    ap.add_argument("--level-budget", type=int, default=0, help="descent levels per slot per launch (0 unlimited)")
+    ap.add_argument("--pipeline", type=int, default=1, choices=[1, 2],
+                    help="2: two half-batches on two streams, tree kernel of one half under the net of the other")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=200, help="event-timed eager steps for the roofline")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -101,12 +104,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if rank == 0:
         entry.build()
+    # rehearsal knobs (one-GPU box): C4_BENCH_BACKEND=gloo C4_BENCH_DEVICE=0 run several ranks on one card
+    backend = os.environ.get("C4_BENCH_BACKEND", "nccl")
+    if "C4_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["C4_BENCH_DEVICE"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         dist.barrier()   # rank 0 has finished building
     torch.cuda.set_device(local_rank)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     from connect4_amd.config import MCTSConfig
     from connect4_amd.net import InferenceNet, NetConfig, random_init_state_dict
@@ -127,7 +137,7 @@ def main():
     sp = SelfPlay(net, args.slots, MCTSConfig.self_play(args.sims), seed=rank, device=local_rank,
                   games_target=-1, record_capacity_games=2 * args.slots, planes_dtype=tdt,
                   use_graph=not args.no_graph, steps_per_graph=args.steps_per_graph, max_inner_iters=args.max_inner,
-                  eval_cache_log2_entries=args.eval_cache)
+                  eval_cache_log2_entries=args.eval_cache, level_budget=args.level_budget, pipeline=args.pipeline)
 
     def barrier():
         if world > 1:
@@ -147,10 +157,10 @@ def main():
     delta = {k: s1[k] - s0[k] for k in s1}
 
     # max elapsed over ranks, sum of units over ranks
-    tens = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tens = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     units = torch.tensor([delta["expansions"], delta["simulations"], delta["games_finished"], delta["moves"],
                           delta["leaf_evals"], delta["terminal_sims"], delta["depth_sum"], delta["children_created"]],
-                         dtype=torch.float64, device="cuda")
+                         dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tens, op=dist.ReduceOp.MAX)
         dist.all_reduce(units, op=dist.ReduceOp.SUM)
@@ -226,7 +236,7 @@ def main():
                 "slots_per_gpu": args.slots, "simulations": args.sims, "net": "32f-3res-4fc",
                 "net_impl": args.net, "net_dtype": args.net_dtype, "tree_dtype": "u64 bitboards, u32 visits, f64 value sums/priors",
                 "parallelism": "games sharded over %d GPU(s), no collective in the rollout path" % world,
-                "max_inner_iters": args.max_inner, "eval_cache_log2_entries": args.eval_cache, "hip_graph": (not args.no_graph), "steps_per_graph": args.steps_per_graph,
+                "max_inner_iters": args.max_inner, "eval_cache_log2_entries": args.eval_cache, "level_budget": args.level_budget, "pipeline_halves": args.pipeline, "hip_graph": (not args.no_graph), "steps_per_graph": args.steps_per_graph,
                 "dirichlet_alpha": 0.3, "exploration_fraction": 0.25, "num_sampling_moves": 6,
             },
         }

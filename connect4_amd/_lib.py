@@ -33,7 +33,7 @@ class Config(C.Structure):
                 ("num_sampling_moves", C.c_int32), ("eval_mode", C.c_int32), ("rng_mode", C.c_int32),
                 ("seed", C.c_uint64), ("stop_after_move", C.c_int32), ("games_target", C.c_int64),
                 ("record_capacity_games", C.c_int32), ("max_inner_iters", C.c_int32),
-                ("planes_dtype", C.c_int32), ("eval_cache_log2_entries", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("planes_dtype", C.c_int32), ("eval_cache_log2_entries", C.c_int32), ("level_budget", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class Stats(C.Structure):
@@ -82,6 +82,7 @@ SIGNATURES = {
     "c4_reset": (C.c_int, [C.c_void_p, _u64p, _u64p, C.c_int32]),
     "c4_set_tapes": (C.c_int, [C.c_void_p, _f64p, _f64p, C.c_int32]),
     "c4_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c4_step_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "c4_run_centre": (C.c_int, [C.c_void_p, C.c_int32]),
     "c4_leaf_buffers": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p), _P(C.c_void_p)]),
     "c4_read_leaves": (C.c_int, [C.c_void_p, _u64p, _u64p, _i32p]),

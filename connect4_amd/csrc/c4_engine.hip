@@ -37,7 +37,7 @@ namespace {
 using namespace c4;
 
 constexpr int GROUP = 8;            // lanes per slot
-constexpr int SLOTS_PER_BLOCK = 8;  // one wave64 per block
+constexpr int SLOTS_PER_BLOCK = 8;  // one wave64 per block (2 or 4 slots per wave measured the same)
 constexpr int BLOCK = GROUP * SLOTS_PER_BLOCK;
 constexpr int MAX_DEPTH = 44;       // root + 42 plies + 1
 
@@ -123,6 +123,8 @@ struct Dev {
     uint32_t *ply;
     long long *game_id;
     PathEntry *path;         // [G][MAX_DEPTH]
+    uint32_t *cont_cur, *cont_n;   // a descent suspended by the level budget: current node, its N ...
+    double *cont_w;                // ... and W (its info lives in pending_info, the board in leaf_c0/1)
     uint64_t *stats;         // [G][N_STATS]
     // per-slot result of the last chosen move
     int32_t *res_move;
@@ -145,6 +147,7 @@ struct Dev {
     unsigned long long *next_game;
     // config
     int G;
+    int slot_lo, slot_hi;    // slots advanced by this launch (c4_step_range; whole engine by default)
     uint32_t cap;
     int S;
     int nsm;
@@ -152,6 +155,7 @@ struct Dev {
     int rng_tape;
     int stop_after_move;
     int max_inner;
+    int level_budget;        // descent levels a slot may walk per launch (0 = unlimited)
     int planes_dtype;
     int rec_cap;
     long long games_target;
@@ -376,8 +380,8 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
 
     const int lane = threadIdx.x & (GROUP - 1);
     const int gl = threadIdx.x / GROUP;
-    const int g = blockIdx.x * SLOTS_PER_BLOCK + gl;
-    if (g >= d.G) return;
+    const int g = d.slot_lo + blockIdx.x * SLOTS_PER_BLOCK + gl;
+    if (g >= d.slot_hi) return;
     if (d.state[g] != SLOT_ACTIVE) {
         if (lane == 0) d.has_leaf[g] = 0;
         return;
@@ -427,6 +431,11 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
     stamp(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(1);
+    // A slot may walk at most `level_budget` descent levels per launch; a descent that runs out is
+    // suspended (node, board and path are saved) and resumed by the next launch.  Every wave then
+    // does about the same amount of work per launch instead of waiting for the deepest tree.
+    int levels_left = d.level_budget > 0 ? d.level_budget : 0x7fffffff;
+    bool resume = (pend == -2);
     int inner = 0;
     for (;;) {
         // ---------------------------------------------------------------- evaluate_node + expand + backup
@@ -651,23 +660,40 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
         }
 
         // bound the launch: at most max_inner evaluator-free simulations per launch
-        if (inner >= d.max_inner) {
+        if (!resume && (inner >= d.max_inner || levels_left <= 0)) {
             st.capped += 1;
             break;
         }
         inner += 1;
 
         // ---------------------------------------------------------------- descent (mcts.py:108-116)
-        uint32_t cur = 0;
-        uint32_t cinfo = pool.info(0);
-        uint32_t cN = pool.n(0);
-        double cW = pool.w(0);
-        uint64_t b0 = root0, b1 = root1;
+        uint32_t cur = 0, cinfo, cN, depth = 0;
+        double cW;
+        uint64_t b0, b1;
+        if (resume) {            // pick a suspended descent up where the previous launch left it
+            resume = false;
+            cur = d.cont_cur[g];
+            cinfo = pinfo;
+            cN = d.cont_n[g];
+            cW = d.cont_w[g];
+            b0 = d.leaf_c0[g];
+            b1 = d.leaf_c1[g];
+            depth = pdepth;
+            for (uint32_t i = lane; i <= depth; i += GROUP) s_path[gl][i] = gpath[i];
+            pend = -1;
+        } else {
+            const Rec rr = *pool.rec(0);
+            cinfo = rr.info;
+            cN = rr.n;
+            cW = rr.w;
+            b0 = root0;
+            b1 = root1;
+            if (lane == 0) s_path[gl][0] = PathEntry{0u, cN, cW};
+        }
         int age = popc64(b0 | b1);
-        uint32_t depth = 0;
-        if (lane == 0) s_path[gl][0] = PathEntry{0u, cN, cW};
         unsigned long long lvl_t0 = d.stamps ? __builtin_amdgcn_s_memtime() : 0, lvl_wait = 0, lvl_alu = 0, lvl_cnt = 0;
-        while (info_status(cinfo) == ST_EVALUATED) {
+        while (info_status(cinfo) == ST_EVALUATED && levels_left > 0) {
+            levels_left -= 1;
             const uint32_t cb = info_base(cinfo), nc = info_nchild(cinfo), pf64 = info_pf64(cinfo);
             if (cN == 1) st.expansions += 1;   // first descent through an evaluated node == expand_node
             const bool act = lane < (int)nc;
@@ -710,6 +736,21 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
         if (d.stamps && blockIdx.x < 256 && threadIdx.x == 0) {
             d.stamps[blockIdx.x * 8 + 7] = (lvl_wait << 32) | (lvl_alu & 0xffffffffu);
             d.stamps[blockIdx.x * 8 + 6] = ((unsigned long long)lvl_cnt << 32) | depth;
+        }
+        if (info_status(cinfo) == ST_EVALUATED) {   // level budget exhausted mid-descent: suspend
+            group_fence();
+            for (uint32_t i = lane; i <= depth; i += GROUP) gpath[i] = s_path[gl][i];
+            if (lane == 0) {
+                d.cont_cur[g] = cur;
+                d.cont_n[g] = cN;
+                d.cont_w[g] = cW;
+                d.leaf_c0[g] = b0;
+                d.leaf_c1[g] = b1;
+            }
+            pend = -2;
+            pdepth = depth;
+            pinfo = cinfo;
+            break;
         }
         st.depth_sum += depth;
         stamp(3);
@@ -784,7 +825,7 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
         d.root_c1[g] = root1;
         d.sims_done[g] = sims;
         d.n_alloc[g] = nalloc;
-        d.pending[g] = has_leaf ? pend : -1;
+        d.pending[g] = (has_leaf || pend == -2) ? pend : -1;
         d.pending_depth[g] = pdepth;
         d.pending_info[g] = pinfo;
         d.need_root[g] = need_root;
@@ -1041,6 +1082,8 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     Dev &d = e->d;
     const size_t G = (size_t)cfg->n_slots;
     d.G = cfg->n_slots;
+    d.slot_lo = 0;
+    d.slot_hi = cfg->n_slots;
     d.cap = (uint32_t)cap;
     d.S = cfg->simulations;
     d.nsm = cfg->num_sampling_moves;
@@ -1051,6 +1094,7 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     d.stop_after_move = cfg->stop_after_move ? 1 : 0;
     d.max_inner = cfg->max_inner_iters > 0 ? cfg->max_inner_iters
                                             : (cfg->eval_mode == C4_EVAL_CENTRE ? 1 << 20 : 1);
+    d.level_budget = cfg->level_budget > 0 ? cfg->level_budget : 0;
     d.planes_dtype = cfg->planes_dtype;
     d.games_target = cfg->games_target;
     d.seed = cfg->seed;
@@ -1068,6 +1112,7 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     ALLOC(d.sims_done, G); ALLOC(d.n_alloc, G); ALLOC(d.state, G); ALLOC(d.need_root, G);
     ALLOC(d.ply, G); ALLOC(d.game_id, G);
     ALLOC(d.path, G * MAX_DEPTH);
+    ALLOC(d.cont_cur, G); ALLOC(d.cont_n, G); ALLOC(d.cont_w, G);
     ALLOC(d.stats, G * N_STATS);
     ALLOC(d.res_move, G); ALLOC(d.res_value, G); ALLOC(d.res_policy, G * 7);
     ALLOC(d.next_game, 1);
@@ -1194,26 +1239,38 @@ int c4_set_tapes(c4_engine *e, const double *gamma_noise, const double *uniforms
     return C4_OK;
 }
 
-int c4_step(c4_engine *e, const void *values_dev, const void *priors_dev, void *planes_dev)
+int c4_step_range(c4_engine *e, const void *values_dev, const void *priors_dev, void *planes_dev, int32_t slot_lo,
+                  int32_t slot_count, void *hip_stream)
 {
     if (!e) return C4_EINVAL;
+    if (slot_lo < 0 || slot_count <= 0 || slot_lo + slot_count > e->d.G || (slot_lo % SLOTS_PER_BLOCK)) { set_err(e->err, "c4_step_range: bad slot range [%d,+%d) (start must be a multiple of %d)", slot_lo, slot_count, SLOTS_PER_BLOCK); return C4_EINVAL; }
     if (e->d.rng_tape && (e->d.use_noise || e->d.nsm > 0) && !e->d.noise_tape) { set_err(e->err, "C4_RNG_TAPE engine needs c4_set_tapes before stepping"); return C4_ESTATE; }
     if (e->cfg.eval_mode != C4_EVAL_CENTRE && e->launches > 0 && (!values_dev || !priors_dev)) { set_err(e->err, "c4_step: values/priors are required after the first step"); return C4_EINVAL; }
-    const dim3 grid((e->d.G + SLOTS_PER_BLOCK - 1) / SLOTS_PER_BLOCK), block(BLOCK);
+    Dev d = e->d;
+    d.slot_lo = slot_lo;
+    d.slot_hi = slot_lo + slot_count;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    const dim3 grid((slot_count + SLOTS_PER_BLOCK - 1) / SLOTS_PER_BLOCK), block(BLOCK);
     switch (e->cfg.eval_mode) {
     case C4_EVAL_EXTERNAL_F32:
-        hipLaunchKernelGGL(c4_step_kernel<C4_EVAL_EXTERNAL_F32>, grid, block, 0, e->stream, e->d, values_dev, priors_dev, planes_dev);
+        hipLaunchKernelGGL(c4_step_kernel<C4_EVAL_EXTERNAL_F32>, grid, block, 0, st, d, values_dev, priors_dev, planes_dev);
         break;
     case C4_EVAL_EXTERNAL_F64:
-        hipLaunchKernelGGL(c4_step_kernel<C4_EVAL_EXTERNAL_F64>, grid, block, 0, e->stream, e->d, values_dev, priors_dev, planes_dev);
+        hipLaunchKernelGGL(c4_step_kernel<C4_EVAL_EXTERNAL_F64>, grid, block, 0, st, d, values_dev, priors_dev, planes_dev);
         break;
     default:
-        hipLaunchKernelGGL(c4_step_kernel<C4_EVAL_CENTRE>, grid, block, 0, e->stream, e->d, values_dev, priors_dev, planes_dev);
+        hipLaunchKernelGGL(c4_step_kernel<C4_EVAL_CENTRE>, grid, block, 0, st, d, values_dev, priors_dev, planes_dev);
         break;
     }
     HIPCHK(e, hipGetLastError());
     e->launches += 1;
     return C4_OK;
+}
+
+int c4_step(c4_engine *e, const void *values_dev, const void *priors_dev, void *planes_dev)
+{
+    if (!e) return C4_EINVAL;
+    return c4_step_range(e, values_dev, priors_dev, planes_dev, 0, e->d.G, nullptr);
 }
 
 int c4_get_stats(c4_engine *e, c4_stats *out)

@@ -25,7 +25,7 @@ class Engine:
                  root_dirichlet_alpha=0.0, root_exploration_fraction=0.0, num_sampling_moves=0,
                  eval_mode=L.EVAL_EXTERNAL_F32, rng_mode=L.RNG_PHILOX, seed=0, stop_after_move=False,
                  games_target=-1, record_capacity_games=0, max_inner_iters=0,
-                 planes_dtype=L.PLANES_F32, eval_cache_log2_entries=0, device=0):
+                 planes_dtype=L.PLANES_F32, eval_cache_log2_entries=0, level_budget=0, device=0):
         self._lib = L.load()
         self.cfg = L.Config()
         self.cfg.abi_version = L.ABI_VERSION
@@ -45,6 +45,7 @@ class Engine:
         self.cfg.max_inner_iters = int(max_inner_iters)
         self.cfg.planes_dtype = int(planes_dtype)
         self.cfg.eval_cache_log2_entries = int(eval_cache_log2_entries)
+        self.cfg.level_budget = int(level_budget)
         self.n_slots = int(n_slots)
         self.device = int(device)
         self._h = C.c_void_p()
@@ -105,6 +106,12 @@ class Engine:
         self.step_ptrs(0 if values is None else values.data_ptr(),
                        0 if priors is None else priors.data_ptr(),
                        0 if planes is None else planes.data_ptr())
+
+    def step_range(self, values, priors, planes, slot_lo, slot_count, stream=0):
+        self._check(self._lib.c4_step_range(
+            self._h, C.c_void_p(0 if values is None else values.data_ptr()),
+            C.c_void_p(0 if priors is None else priors.data_ptr()),
+            C.c_void_p(0 if planes is None else planes.data_ptr()), int(slot_lo), int(slot_count), C.c_void_p(stream or 0)))
 
     def run_centre(self, max_launches=64):
         self._check(self._lib.c4_run_centre(self._h, int(max_launches)))

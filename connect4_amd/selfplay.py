@@ -26,7 +26,7 @@ class SelfPlay:
     def __init__(self, net: Callable, n_slots: int, config: MCTSConfig, seed: int = 0, device: int = 0,
                  games_target: int = -1, record_capacity_games: int = 0, planes_dtype=torch.float32,
                  use_graph: bool = True, steps_per_graph: int = 8, max_inner_iters: int = 0,
-                 eval_cache_log2_entries: int = 0):
+                 eval_cache_log2_entries: int = 0, level_budget: int = 0, pipeline: int = 1):
         self.net = net
         self.n_slots = n_slots
         self.config = config
@@ -34,13 +34,17 @@ class SelfPlay:
         self.engine = Engine(n_slots, eval_mode=L.EVAL_EXTERNAL_F32, rng_mode=L.RNG_PHILOX, seed=seed,
                              stop_after_move=False, games_target=games_target,
                              record_capacity_games=record_capacity_games, max_inner_iters=max_inner_iters,
-                             planes_dtype=_PLANES[planes_dtype], eval_cache_log2_entries=eval_cache_log2_entries,
+                             planes_dtype=_PLANES[planes_dtype], eval_cache_log2_entries=eval_cache_log2_entries, level_budget=level_budget,
                              device=device, **config.engine_kwargs())
         with torch.cuda.device(self.device):
             self.values = torch.zeros(n_slots, dtype=torch.float32, device=self.device)
             self.priors = torch.full((n_slots, 7), 1.0 / 7.0, dtype=torch.float32, device=self.device)
             self.planes = torch.zeros(n_slots, 3, 6, 7, dtype=planes_dtype, device=self.device)
         self._bits = bool(getattr(net, "from_bitboards", False))   # fused kernel reads the leaf bitboards
+        # pipeline=2: the batch is split in two halves on two HIP streams, phase-shifted, so the
+        # (latency-bound) tree kernel of one half runs under the (MFMA-bound) network of the other
+        self._pipeline = 2 if (pipeline == 2 and self._bits and n_slots % 16 == 0) else 1
+        self._streams = None
         self._leaf_c0, self._leaf_c1, _ = self.engine.leaf_buffers()
         self.steps_done = 0
         self.steps_per_graph = max(1, steps_per_graph)
@@ -48,7 +52,34 @@ class SelfPlay:
         self._use_graph = use_graph
 
     # one rollout step = tree kernel (apply previous answers, select, emit leaves) + leaf evaluation
+    def _net_range(self, lo, cnt, stream):
+        self.net.forward_bitboards(self._leaf_c0 + 8 * lo, self._leaf_c1 + 8 * lo, cnt, self.values[lo:lo + cnt],
+                                   self.priors[lo:lo + cnt], stream.cuda_stream)
+
+    def _steps_pipelined(self, k):
+        """k rounds for both halves: A = tree,net,tree,net...  B = net,tree,net,tree..."""
+        cur = torch.cuda.current_stream(self.device)
+        if self._streams is None:
+            self._streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+        sa, sb = self._streams
+        half = self.n_slots // 2
+        sa.wait_stream(cur)
+        sb.wait_stream(cur)
+        with torch.cuda.stream(sa):
+            for _ in range(k):
+                self.engine.step_range(self.values, self.priors, None, 0, half, sa.cuda_stream)
+                self._net_range(0, half, sa)
+        with torch.cuda.stream(sb):
+            for _ in range(k):
+                self._net_range(half, self.n_slots - half, sb)
+                self.engine.step_range(self.values, self.priors, None, half, self.n_slots - half, sb.cuda_stream)
+        cur.wait_stream(sa)
+        cur.wait_stream(sb)
+
     def _step_eager(self):
+        if self._pipeline == 2:
+            self._steps_pipelined(1)
+            return
         stream = torch.cuda.current_stream(self.device).cuda_stream
         self.engine.set_stream(stream)
         if self._bits:
@@ -72,8 +103,11 @@ class SelfPlay:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                for _ in range(self.steps_per_graph):
-                    self._step_eager()
+                if self._pipeline == 2:
+                    self._steps_pipelined(self.steps_per_graph)
+                else:
+                    for _ in range(self.steps_per_graph):
+                        self._step_eager()
             self._graph = g
 
     def run_steps(self, k: int):

@@ -87,7 +87,10 @@ typedef struct {
                                           evaluator round trip.  Results are unchanged for a
                                           deterministic evaluator.  <0 off, 0 auto (on for self-play
                                           with C4_EVAL_EXTERNAL_F32), else log2 of the table size */
-    int32_t reserved[6];
+    int32_t level_budget;              /* descent levels a slot may walk per launch; a descent that runs
+                                          out is suspended and resumed by the next launch, so no launch
+                                          waits for the deepest tree of the batch.  0 = unlimited */
+    int32_t reserved[5];
 } c4_config;
 
 typedef struct c4_engine c4_engine;
@@ -173,6 +176,12 @@ int c4_set_tapes(c4_engine *e, const double *gamma_noise, const double *uniforms
  * order (dtype per eval_mode; ignored by C4_EVAL_CENTRE; may be NULL on the first step).
  * planes_dev may be NULL when the caller evaluates from the bitboards instead. */
 int c4_step(c4_engine *e, const void *values_dev, const void *priors_dev, void *planes_dev);
+
+/* The same step for slots [slot_lo, slot_lo+slot_count) only, on `hip_stream` (NULL = the engine's
+ * stream).  Lets the host pipeline two halves of the batch on two streams: the tree kernel of one half
+ * runs while the network evaluates the other half's leaves.  Buffers stay indexed by absolute slot. */
+int c4_step_range(c4_engine *e, const void *values_dev, const void *priors_dev, void *planes_dev,
+                  int32_t slot_lo, int32_t slot_count, void *hip_stream);
 
 /* C4_EVAL_CENTRE convenience: launch until every slot has parked (stop_after_move) or
  * max_launches is reached.  Synchronous. */

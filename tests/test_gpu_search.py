@@ -169,7 +169,7 @@ def check_selfplay(case, eval_mode, fn=None, **engine_kw):
         eng.set_tapes(nz, u)
         eng.reset()
         if eval_mode == L.EVAL_CENTRE:
-            eng.run_centre(max_launches=4096)
+            eng.run_centre(max_launches=200000)
         else:
             drive_external(eng, fn, np.float32)
         games = eng.drain_games()
@@ -217,7 +217,17 @@ def test_eval_cache_is_transparent():
         def fn(c0, c1):
             seen.append((int(c0), int(c1)))
             return table(c0, c1)
-        st = check_selfplay(case, L.EVAL_EXTERNAL_F32, fn, eval_cache_log2_entries=16, max_inner_iters=4)
+        st = check_selfplay(case, L.EVAL_EXTERNAL_F32, fn, eval_cache_log2_entries=16, max_inner_iters=4,
+                            level_budget=5)
         assert st["eval_cache_hits"] > 0.2 * st["leaf_evals"]
         assert st["eval_cache_hits"] + len(seen) == st["leaf_evals"]
         assert len(seen) - len(set(seen)) <= 0.02 * len(seen)   # re-evaluations only after direct-mapped evictions
+
+
+def test_level_budget_suspension_is_transparent():
+    """A tiny level budget forces most descents to be suspended and resumed across launches; games
+    must still equal the golden ones move for move (centre evaluator, RNG tape)."""
+    from connect4_amd import _lib as L
+    for case in load_json("selfplay.json")[:2]:
+        st = check_selfplay(case, L.EVAL_CENTRE, level_budget=3, max_inner_iters=2)
+        assert st["capped_slots"] > 0

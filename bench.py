@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--level-budget", type=int, default=0, help="descent levels per slot per launch (0 unlimited)")
     ap.add_argument("--pipeline", type=int, default=1, choices=[1, 2],
                     help="2: two half-batches on two streams, tree kernel of one half under the net of the other")
+    ap.add_argument("--fused-loop", type=int, default=1, help="1: tree step + net in one persistent kernel")
+    ap.add_argument("--steps-per-launch", type=int, default=32)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=200, help="event-timed eager steps for the roofline")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -137,7 +139,8 @@ def main():
     sp = SelfPlay(net, args.slots, MCTSConfig.self_play(args.sims), seed=rank, device=local_rank,
                   games_target=-1, record_capacity_games=2 * args.slots, planes_dtype=tdt,
                   use_graph=not args.no_graph, steps_per_graph=args.steps_per_graph, max_inner_iters=args.max_inner,
-                  eval_cache_log2_entries=args.eval_cache, level_budget=args.level_budget, pipeline=args.pipeline)
+                  eval_cache_log2_entries=args.eval_cache, level_budget=args.level_budget, pipeline=args.pipeline,
+                  fused_loop=bool(args.fused_loop), steps_per_launch=args.steps_per_launch)
 
     def barrier():
         if world > 1:
@@ -236,7 +239,7 @@ def main():
                 "slots_per_gpu": args.slots, "simulations": args.sims, "net": "32f-3res-4fc",
                 "net_impl": args.net, "net_dtype": args.net_dtype, "tree_dtype": "u64 bitboards, u32 visits, f64 value sums/priors",
                 "parallelism": "games sharded over %d GPU(s), no collective in the rollout path" % world,
-                "max_inner_iters": args.max_inner, "eval_cache_log2_entries": args.eval_cache, "level_budget": args.level_budget, "pipeline_halves": args.pipeline, "hip_graph": (not args.no_graph), "steps_per_graph": args.steps_per_graph,
+                "max_inner_iters": args.max_inner, "eval_cache_log2_entries": args.eval_cache, "level_budget": args.level_budget, "pipeline_halves": args.pipeline, "fused_loop": bool(args.fused_loop), "steps_per_launch": args.steps_per_launch, "hip_graph": (not args.no_graph), "steps_per_graph": args.steps_per_graph,
                 "dirichlet_alpha": 0.3, "exploration_fraction": 0.25, "num_sampling_moves": 6,
             },
         }
@@ -248,31 +251,38 @@ def main():
             pass
         if prof:
             ach = prof["tree_bytes_per_launch"] / (prof["tree_ms"] * 1e-3) / 1e9
-            out["roofline_tree"] = {
-                "kernel": "c4_step_kernel<EXTERNAL_F32> (tree walk: apply+backup, PUCT descent, expand, emit)",
+            pmc_ok = args.slots == 4096 and args.sims == 800 and args.max_inner == pmc.get("max_inner", -1)
+            tree = {
+                "kernel": "c4_step_kernel<EXTERNAL_F32> (tree walk: apply+backup, PUCT descent, expand, move choice, emit)",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS,
                 # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
                 # command (profiles/r01_pmc_traffic.json, KB -> bytes, uncorrected: gfx950 may under-count
                 # reads by up to 2x, MI355X_MICROARCH.md section HBM); not collectable inside this process
-                "traffic": ((pmc["FETCH_SIZE_tree"] + pmc["WRITE_SIZE_tree"]) * 1024.0
-                            if args.slots == 4096 and args.sims == 800 and "FETCH_SIZE_tree" in pmc else None),
-                "event_overhead_ms_subtracted": prof["ev_overhead_ms"],
-                "avg_launch_ms": prof["tree_ms"], "sims_per_launch": prof["sims_per_launch"],
-                "mean_depth": prof["mean_depth"], "algorithmic_bytes_per_launch": prof["tree_bytes_per_launch"],
+                "traffic": ((pmc["FETCH_SIZE_tree"] + pmc["WRITE_SIZE_tree"]) * 1024.0 if pmc_ok and "FETCH_SIZE_tree" in pmc else None),
+                "avg_launch_ms": prof["tree_ms"], "event_overhead_ms_subtracted": prof["ev_overhead_ms"],
+                "sims_per_launch": prof["sims_per_launch"], "mean_depth": prof["mean_depth"],
+                "algorithmic_bytes_per_launch": prof["tree_bytes_per_launch"],
                 "note": "dependent-load (latency) bound pointer chase; bytes = (136*D+332) per simulation",
             }
             tf = NET_MFLOP_PER_POSITION * 1e6 * args.slots / (prof["net_ms"] * 1e-3) / 1e12
             peak = FP32_MATRIX_PEAK_TF if args.net_dtype == "f32" else BF16_MFMA_PEAK_TF
-            out["roofline"] = {   # the dominant kernel by time is the leaf-batch network
-                "share_of_step": prof["net_ms"] / (prof["net_ms"] + prof["tree_ms"]),
+            net_leaves = (p1["leaf_evals"] - p0["leaf_evals"] - (p1["eval_cache_hits"] - p0["eval_cache_hits"])) / len(ev)
+            netr = {
                 "kernel": ("c4_net_kernel (fused stem+tower+heads, v_mfma_f32_32x32x16_f16)" if args.net == "fused"
                            else "leaf-batch policy/value net forward (PyTorch-ROCm / MIOpen convs)"),
                 "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                 "avg_forward_ms": prof["net_ms"],
                 "traffic": ((pmc["FETCH_SIZE_net"] + pmc["WRITE_SIZE_net"]) * 1024.0
-                            if args.slots == 4096 and args.net == "fused" and "FETCH_SIZE_net" in pmc else None),
+                            if pmc_ok and args.net == "fused" and "FETCH_SIZE_net" in pmc else None),
+                "positions_per_launch": args.slots, "leaves_needing_the_net_per_launch": net_leaves,
+                "note": "achieved counts every row the kernel computes (static batch); slots whose simulation "
+                        "ended on a terminal or cached leaf still occupy a row",
             }
+            out["roofline_tree"] = tree
+            out["roofline_net"] = netr
+            out["roofline"] = dict(tree if prof["tree_ms"] >= prof["net_ms"] else netr)   # the dominant kernel by time
+            out["roofline"]["share_of_step"] = max(prof["tree_ms"], prof["net_ms"]) / (prof["tree_ms"] + prof["net_ms"])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, args.sims, args.cpu_seconds, 256)
         print(json.dumps(out))

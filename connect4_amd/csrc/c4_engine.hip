@@ -31,6 +31,7 @@
 
 #include "../../include/c4_engine.h"
 #include "c4_board.h"
+#include "c4_net_dev.h"
 
 namespace {
 
@@ -371,16 +372,16 @@ template <> __device__ __forceinline__ void store_plane<hip_bfloat16>(void *p, s
 // ------------------------------------------------------------------------------------------
 // the rollout-step kernel
 // ------------------------------------------------------------------------------------------
-template <int EVAL>
-__global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__restrict__ values_in,
-                                                        const void *__restrict__ priors_in,
-                                                        void *__restrict__ planes_out)
+// One rollout step of slot `g` by its 8-lane group (`gl` = the group's row in s_path).  Called by the
+// standalone step kernel and by the fused self-play kernel.  `leaf_out` (optional, LDS or global) gets
+// the emitted leaf's bitboards {color0, color1} or {0,0} when the slot emits nothing.
+template <int EVAL, bool STAMPS = true>
+__device__ __forceinline__ void tree_step(const Dev &d, const int g, const int lane, const int gl,
+                                          PathEntry (*s_path)[MAX_DEPTH], const void *__restrict__ values_in,
+                                          const void *__restrict__ priors_in, void *__restrict__ planes_out,
+                                          uint64_t *leaf_out)
 {
-    __shared__ PathEntry s_path[SLOTS_PER_BLOCK][MAX_DEPTH];
-
-    const int lane = threadIdx.x & (GROUP - 1);
-    const int gl = threadIdx.x / GROUP;
-    const int g = d.slot_lo + blockIdx.x * SLOTS_PER_BLOCK + gl;
+    if (leaf_out && lane < 2) leaf_out[lane] = 0;
     if (g >= d.slot_hi) return;
     if (d.state[g] != SLOT_ACTIVE) {
         if (lane == 0) d.has_leaf[g] = 0;
@@ -403,7 +404,9 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
     long long gid = d.game_id[g];
     int state = SLOT_ACTIVE;
     int has_leaf = 0;
-    SlotStats st = {};
+    struct { uint32_t sims, expansions, children, terminal_sims, leaf_evals, depth_sum, moves, games_started,
+                      games_finished, capped, cache_hits, cache_probes; } st = {};
+    static_assert(sizeof(st) == N_STATS * 4, "launch-local stats mirror SlotStats");
 
     // evaluator answer for the pending leaf
     uint64_t leaf0 = 0, leaf1 = 0;
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
     }
 
     auto stamp = [&](int i) {
-        if (d.stamps && blockIdx.x < 256 && threadIdx.x == 0) d.stamps[blockIdx.x * 8 + i] = __builtin_amdgcn_s_memtime();
+        if (STAMPS && d.stamps && blockIdx.x < 256 && threadIdx.x == 0) d.stamps[blockIdx.x * 8 + i] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
                     const double last = gshfl(cdf, (int)nc - 1);
                     cdf = cdf / last;
                     const unsigned long long bal = __ballot(act && cdf <= u);
-                    int cnt = __popcll((bal >> (gl * GROUP)) & 0xffull);
+                    int cnt = __popcll((bal >> (((threadIdx.x & 63) / GROUP) * GROUP)) & 0xffull);
                     kb = cnt < (int)nc ? cnt : (int)nc - 1;
                 }
             }
@@ -691,7 +694,7 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
             if (lane == 0) s_path[gl][0] = PathEntry{0u, cN, cW};
         }
         int age = popc64(b0 | b1);
-        unsigned long long lvl_t0 = d.stamps ? __builtin_amdgcn_s_memtime() : 0, lvl_wait = 0, lvl_alu = 0, lvl_cnt = 0;
+        unsigned long long lvl_t0 = (STAMPS && d.stamps) ? __builtin_amdgcn_s_memtime() : 0, lvl_wait = 0, lvl_alu = 0, lvl_cnt = 0;
         while (info_status(cinfo) == ST_EVALUATED && levels_left > 0) {
             levels_left -= 1;
             const uint32_t cb = info_base(cinfo), nc = info_nchild(cinfo), pf64 = info_pf64(cinfo);
@@ -704,7 +707,7 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
             const double w = r.w, q = r.q, p = r.p;
             const double2 ab = d.tabAB[cN];
             const double A = ab.x, B = ab.y;
-            if (d.stamps) {   // diagnostic: cycles spent waiting for this level's loads
+            if (STAMPS && d.stamps) {   // diagnostic: cycles spent waiting for this level's loads
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime();
                 lvl_wait += t1 - lvl_t0;
@@ -726,14 +729,14 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
             age += 1;
             depth += 1;
             if (lane == 0) s_path[gl][depth] = PathEntry{cur, cN, cW};
-            if (d.stamps) {
+            if (STAMPS && d.stamps) {
                 const unsigned long long t2 = __builtin_amdgcn_s_memtime();
                 lvl_alu += t2 - lvl_t0;
                 lvl_t0 = t2;
                 lvl_cnt += 1;
             }
         }
-        if (d.stamps && blockIdx.x < 256 && threadIdx.x == 0) {
+        if (STAMPS && d.stamps && blockIdx.x < 256 && threadIdx.x == 0) {
             d.stamps[blockIdx.x * 8 + 7] = (lvl_wait << 32) | (lvl_alu & 0xffffffffu);
             d.stamps[blockIdx.x * 8 + 6] = ((unsigned long long)lvl_cnt << 32) | depth;
         }
@@ -808,6 +811,7 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
     stamp(4);
     if (has_leaf) {
         if (lane == 0) { d.leaf_c0[g] = leaf0; d.leaf_c1[g] = leaf1; }
+        if (leaf_out && lane == 0) { leaf_out[0] = leaf0; leaf_out[1] = leaf1; }
         if (planes_out) {
             const int o_to_move = (popc64(leaf0 | leaf1) & 1) ? 0 : 1;
             const size_t pb = (size_t)g * 126;
@@ -833,12 +837,74 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
         d.game_id[g] = gid;
         d.state[g] = state;
         uint64_t *sp = d.stats + (size_t)g * N_STATS;
-        const uint64_t *sv = (const uint64_t *)&st;
+        const uint32_t *sv = (const uint32_t *)&st;
 #pragma unroll
         for (int i = 0; i < N_STATS; ++i) sp[i] += sv[i];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(5);
+}
+
+template <int EVAL>
+__global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__restrict__ values_in,
+                                                        const void *__restrict__ priors_in,
+                                                        void *__restrict__ planes_out)
+{
+    __shared__ PathEntry s_path[SLOTS_PER_BLOCK][MAX_DEPTH];
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int gl = threadIdx.x / GROUP;
+    const int g = d.slot_lo + blockIdx.x * SLOTS_PER_BLOCK + gl;
+    tree_step<EVAL>(d, g, lane, gl, s_path, values_in, priors_in, planes_out, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
+// fused persistent self-play kernel: one workgroup = 16 slots = one CU-sized unit that alternates
+//   tree phase  (waves 0-1: the slots' 8-lane groups run tree_step)
+//   net phase   (all 8 waves: net_forward_block on the 16 leaves, straight from LDS)
+// for n_steps rounds with NO kernel boundary, no inter-workgroup traffic and no global barrier:
+// a workgroup only ever waits for its own 16 trees, not for the deepest tree of the whole batch.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4net::NetDev nd, float *__restrict__ values,
+                                                                      float *__restrict__ priors, int n_steps)
+{
+    using namespace c4net;
+    __shared__ __attribute__((aligned(16))) _Float16 act[2][(ROWS + 1) * CS];
+    __shared__ __attribute__((aligned(16))) half8 wbuf[2][WCHUNKS];
+    __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
+    __shared__ uint64_t sleaf[2][P];   // leaf bitboards handed from the tree phase to the net phase
+    static_assert(sizeof(PathEntry) * MAX_DEPTH * P <= sizeof(_Float16) * ROWS * CS, "path stack must fit the activation buffer");
+    // the tree phase's path stacks live in activation buffer 0, which the net overwrites afterwards
+    PathEntry (*s_path)[MAX_DEPTH] = reinterpret_cast<PathEntry (*)[MAX_DEPTH]>(&act[0][0]);
+    const int slot0 = blockIdx.x * P;
+    const int lane = threadIdx.x & (GROUP - 1);
+    // two slots per wave (lanes 0..15), all 8 waves busy: slots that sit in one wave execute in SIMT
+    // lock-step and wait for each other's deeper trees, so spreading them over waves shortens the phase
+    const int wv = threadIdx.x >> 6, grp = (threadIdx.x & 63) / GROUP;
+    const int sl = wv + NWAVES * grp;     // slot of this 8-lane group inside the workgroup (grp < 2)
+    unsigned long long t_tree = 0, t_net = 0, t_own = 0;   // diagnostic (C4_TREE_STAMPS=1)
+    for (int step = 0; step < n_steps; ++step) {
+        const unsigned long long ta = d.stamps ? __builtin_amdgcn_s_memtime() : 0;
+        if (grp < P / NWAVES) tree_step<C4_EVAL_EXTERNAL_F32, false>(d, slot0 + sl, lane, sl, s_path, values, priors, nullptr, nullptr);
+        const unsigned long long tb = d.stamps ? __builtin_amdgcn_s_memtime() : 0;
+        __syncthreads();   // tree-phase global stores (leaf boards, node records) are visible to the whole CU
+        const unsigned long long tc = d.stamps ? __builtin_amdgcn_s_memtime() : 0;
+        t_own += tb - ta;
+        t_tree += tc - ta;
+        if (threadIdx.x < 2 * P) {
+            const int which = threadIdx.x / P, p = threadIdx.x - which * P;
+            sleaf[which][p] = which ? d.leaf_c1[slot0 + p] : d.leaf_c0[slot0 + p];
+        }
+        __syncthreads();
+        net_forward_block(nd, NetLds{act, wbuf, mlp}, sleaf[0], sleaf[1], min(P, d.G - slot0), 0, values + slot0,
+                          priors + (size_t)slot0 * 7);
+        __syncthreads();   // values/priors written; LDS free for the next tree phase
+        if (d.stamps) t_net += __builtin_amdgcn_s_memtime() - tc;
+    }
+    if (d.stamps && blockIdx.x < 256 && (threadIdx.x & 63) == 0) {
+        unsigned long long *o = d.stamps + blockIdx.x * 8;
+        if (wv == 0) { o[0] = t_tree; o[1] = t_net; o[2] = (unsigned long long)n_steps; }
+        if (wv < 5) o[3 + wv] = t_own;   // this wave's own tree work (waves 0..4)
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1264,6 +1330,22 @@ int c4_step_range(c4_engine *e, const void *values_dev, const void *priors_dev, 
     }
     HIPCHK(e, hipGetLastError());
     e->launches += 1;
+    return C4_OK;
+}
+
+int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *priors_dev, int32_t n_steps, void *hip_stream)
+{
+    if (!e || !net || !values_dev || !priors_dev || n_steps <= 0) { if (e) set_err(e->err, "c4_selfplay_steps: bad argument"); return C4_EINVAL; }
+    if (e->cfg.eval_mode != C4_EVAL_EXTERNAL_F32) { set_err(e->err, "c4_selfplay_steps needs C4_EVAL_EXTERNAL_F32"); return C4_ESTATE; }
+    if (e->d.G % c4net::P) { set_err(e->err, "c4_selfplay_steps needs n_slots to be a multiple of %d", c4net::P); return C4_EINVAL; }
+    if (net->device != e->device) { set_err(e->err, "engine and net live on different devices"); return C4_EINVAL; }
+    if (e->d.rng_tape && (e->d.use_noise || e->d.nsm > 0) && !e->d.noise_tape) { set_err(e->err, "C4_RNG_TAPE engine needs c4_set_tapes before stepping"); return C4_ESTATE; }
+    c4net::NetDev nd = net->d;
+    nd.stamps = nullptr;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    hipLaunchKernelGGL(c4_selfplay_kernel, dim3(e->d.G / c4net::P), dim3(c4net::NTHREADS), 0, st, e->d, nd, values_dev, priors_dev, (int)n_steps);
+    HIPCHK(e, hipGetLastError());
+    e->launches += n_steps;
     return C4_OK;
 }
 

@@ -1,0 +1,399 @@
+// c4_net_dev.h -- device side of the fused policy/value network (see c4_net.hip for the design notes):
+// constants, the weight view NetDev, and net_forward_block(), the per-workgroup forward used by both
+// the standalone kernel (c4_net.hip) and the fused self-play kernel (c4_engine.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+namespace c4net {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int F = 32;                 // filters
+constexpr int P = 16;                 // positions per workgroup
+constexpr int PIX = 42;
+constexpr int ROWS = P * PIX;         // 672
+constexpr int TILES = ROWS / 32;      // 21
+constexpr int CS = 40;                // halves per LDS row (32 channels + 8 pad => 80 B stride)
+constexpr int KSTEPS = 18;            // 9 taps x 32 cin / 16
+constexpr int NWAVES = 8;             // two waves per SIMD: one's LDS/epilogue hides under the other's MFMAs
+constexpr int NTHREADS = NWAVES * 64;
+constexpr int WCHUNKS = KSTEPS * 64;  // 16-byte A-fragment chunks per conv layer (18 KiB)
+constexpr int HEADV = 3 * PIX;        // 126 head activations per position
+constexpr int HSTR = 128;             // floats per position in the head scratch (16-byte aligned rows)
+constexpr int VT_F4 = 11 * 64;        // value table: [11 groups of 4 inputs][64 lanes] float4
+constexpr int PT_F = 11 * 64;         // policy table: [11][64] floats (lane = logit + 8*segment)
+constexpr int MLP_F4 = VT_F4 + PT_F / 4 + 3 * 16;   // + fc_b, vout_w, pfc_b (64 floats each) = 928 float4 = 14,848 B
+constexpr float LEAK = 0.01f;
+
+struct NetDev {
+    const half8 *stem_w;   // [3][64]           lane-ordered A fragments
+    const float *stem_b;   // [32]
+    const half8 *conv_w;   // [2R][18][64]
+    const float *conv_b;   // [2R][32]
+    const half8 *head_w;   // [2][64]           couts 0..2 = value, policy0, policy1
+    const float *head_b;   // [4]
+    const float4 *mlp;     // MLP_F4 float4s: value table [11][64][4], policy table [11][64], fc_b[64], vout_w[64], pfc_b[64]
+    float vout_b, w1, w2;
+    int n_res;
+    unsigned long long *stamps;   // diagnostic only (C4_NET_STAMPS=1): [wave][16] s_memtime values of block 0
+};
+
+__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, LEAK * v); }   // slope < 1
+
+// DPP cross-lane moves (VALU speed; ds_bpermute-based __shfl costs an LDS round trip each)
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// sum / max over each aligned group of 8 lanes (quad_perm xor1, xor2, row_half_mirror)
+__device__ __forceinline__ float sum8(float v) { v += dppf<0xB1>(v); v += dppf<0x4E>(v); v += dppf<0x141>(v); return v; }
+__device__ __forceinline__ float max8(float v)
+{
+    v = fmaxf(v, dppf<0xB1>(v)); v = fmaxf(v, dppf<0x4E>(v)); v = fmaxf(v, dppf<0x141>(v));
+    return v;
+}
+// sum over each 16-lane row (+ row_mirror)
+__device__ __forceinline__ float sum16(float v) { v = sum8(v); v += dppf<0x140>(v); return v; }
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// epilogue of one 32-row tile.  Bias enters as the accumulator's initial value and the residual skip
+// as two extra MFMAs against an identity matrix, so what is left is LeakyReLU + fp16 + 4 stores.
+__device__ __forceinline__ void store_tile(const floatx16 &acc, _Float16 *dst, int rowoff, int h)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        half4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (_Float16)lrelu(acc[4 * q + i]);
+        *reinterpret_cast<half4 *>(dst + rowoff + 8 * q + 4 * h) = o;
+    }
+}
+
+__device__ __forceinline__ floatx16 acc_from_bias(const float4 (&b)[4])
+{
+    floatx16 a;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a[4 * q] = b[q].x; a[4 * q + 1] = b[q].y; a[4 * q + 2] = b[q].z; a[4 * q + 3] = b[q].w; }
+    return a;
+}
+
+// LDS carved by the caller (standalone kernel below, or the fused self-play kernel in c4_engine.hip):
+// activations ping-pong 2 x 53,840 B (+ one all-zero row each that out-of-board taps read instead of
+// branching) | conv weights double-buffered 2 x 18,432 B | MLP tables 14,848 B = 159,392 B of 160 KiB.
+struct NetLds {
+    _Float16 (*act)[(ROWS + 1) * CS];   // [2]
+    half8 (*wbuf)[WCHUNKS];             // [2]
+    float4 *mlp;                        // [MLP_F4]
+};
+constexpr size_t NET_LDS_BYTES = 2 * (ROWS + 1) * CS * sizeof(_Float16) + 2 * WCHUNKS * sizeof(half8) + MLP_F4 * sizeof(float4);
+
+// One workgroup (NTHREADS threads) evaluates positions pos0 .. pos0+15.
+__device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds &L, const uint64_t *__restrict__ c0,
+                                                  const uint64_t *__restrict__ c1, int n, int pos0,
+                                                  float *__restrict__ values, float *__restrict__ priors)
+{
+    _Float16 (*lds)[(ROWS + 1) * CS] = L.act;
+    half8 (*wbuf)[WCHUNKS] = L.wbuf;
+    float4 *mlp = L.mlp;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int n_layers = 2 * nd.n_res;
+
+    // conv weights of layer L+1 travel global -> registers -> LDS while layer L computes
+    half8 wpre[3];
+    auto prefetch = [&](int L) {
+        if (L < n_layers) {
+            const half8 *wsrc = nd.conv_w + (size_t)L * WCHUNKS;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = threadIdx.x + i * NTHREADS;
+                if (c < WCHUNKS) wpre[i] = wsrc[c];
+            }
+        }
+    };
+    auto commit = [&](int L) {
+        if (L < n_layers) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = threadIdx.x + i * NTHREADS;
+                if (c < WCHUNKS) wbuf[L & 1][c] = wpre[i];
+            }
+        }
+    };
+    auto stamp = [&](int i) {
+        if (nd.stamps && pos0 == 0 && lane == 0) nd.stamps[wave * 16 + i] = __builtin_amdgcn_s_memtime();
+    };
+    // this lane's 16 output channels are {8q + 4h + 0..3 : q = 0..3}
+    auto load_bias = [&](const float *b, float4 (&out)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[q] = *reinterpret_cast<const float4 *>(b + 8 * q + 4 * h);
+    };
+    stamp(0);
+    prefetch(0);
+    // NN input planes (board.py:147-154) as 4 halves per (position,pixel) row: [to-move, o, x, 0];
+    // they live in lds[1], which the tower only starts writing after the stem is done
+    _Float16 *inp = lds[1];
+    for (int r = threadIdx.x; r <= ROWS; r += NTHREADS) {
+        half4 v = {};
+        if (r < ROWS) {
+            const int p = r / PIX, pix = r - p * PIX;
+            const int y = pix / 7, x = pix - y * 7;
+            const int gp = pos0 + p;
+            const uint64_t b0 = gp < n ? c0[gp] : 0, b1 = gp < n ? c1[gp] : 0;
+            const int bit = x * 7 + (5 - y);                       // row 0 of the planes = top of the board
+            v[0] = (_Float16)((__popcll(b0 | b1) & 1) ? 0.0f : 1.0f);   // board.py:150-152
+            v[1] = (_Float16)(float)((b0 >> bit) & 1);
+            v[2] = (_Float16)(float)((b1 >> bit) & 1);
+        }
+        *reinterpret_cast<half4 *>(inp + r * 4) = v;               // r == ROWS: the zero row of the planes
+    }
+    if (threadIdx.x < CS) lds[0][ROWS * CS + threadIdx.x] = (_Float16)0.0f;                  // zero rows of the two
+    else if (threadIdx.x >= 64 && threadIdx.x < 64 + CS) lds[1][ROWS * CS + threadIdx.x - 64] = (_Float16)0.0f;   // activation buffers
+    {   // MLP tables: 928 float4, used only at the very end
+        const float4 m0 = nd.mlp[threadIdx.x];
+        const float4 m1 = threadIdx.x + NTHREADS < MLP_F4 ? nd.mlp[threadIdx.x + NTHREADS] : float4{0, 0, 0, 0};
+        mlp[threadIdx.x] = m0;
+        if (threadIdx.x + NTHREADS < MLP_F4) mlp[threadIdx.x + NTHREADS] = m1;
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ stem: planes -> lds[0]
+    // K = 9 taps x 4 channels (36, padded to 48 = 3 MFMA steps); a lane's 8 k's are 2 taps x 4 channels,
+    // i.e. two 8-byte reads of the plane rows (out-of-board taps read the zero row)
+    {
+        half8 w[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) w[s] = nd.stem_w[s * 64 + lane];
+        float4 bias[4];
+        load_bias(nd.stem_b, bias);
+        for (int t = wave; t < TILES; t += NWAVES) {
+            const int rg = t * 32 + r32;
+            const int p = rg / PIX, pix = rg - p * PIX;
+            const int y = pix / 7, x = pix - y * 7;
+            half4 v[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int tap = 4 * (i >> 1) + 2 * h + (i & 1);      // k = 16s + 8h + j = tap*4 + channel
+                const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;   // tap/3, tap%3 for tap < 12
+                const int ok = -(int)(tap < 9 && (unsigned)(y + ty - 1) < 6u && (unsigned)(x + tx - 1) < 7u);
+                const int row = ((rg + (ty - 1) * 7 + tx - 1) & ok) | (ROWS & ~ok);
+                v[i] = *reinterpret_cast<const half4 *>(inp + row * 4);
+            }
+            floatx16 acc = acc_from_bias(bias);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                half8 bf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bf[j] = v[2 * s][j]; bf[4 + j] = v[2 * s + 1][j]; }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s], bf, acc, 0, 0, 0);
+            }
+            store_tile(acc, lds[0], rg * CS, h);
+        }
+    }
+    stamp(1);
+    commit(0);
+    __syncthreads();
+    stamp(2);
+
+    // ------------------------------------------------------------------ residual tower
+    // A wave owns tiles wave, wave+8, wave+16 (the last only for waves 0..4) in every layer, so the
+    // per-row LDS offsets of the 9 taps are computed once and kept in registers.
+    constexpr int TPW = (TILES + NWAVES - 1) / NWAVES;   // 3
+    int rsel[TPW][9], rbase[TPW];
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int rg = (wave + ti * NWAVES) * 32 + r32;
+        const int p = rg / PIX, pix = rg - p * PIX;
+        const int y = pix / 7, x = pix - y * 7;
+        rbase[ti] = rg * CS;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            // zero padding without branches: out-of-board taps read the all-zero row (index ROWS)
+            const int ok = -(int)((unsigned)(y + dy) < 6u && (unsigned)(x + dx) < 7u);   // all ones / zero
+            rsel[ti][tap] = (((rg + dy * 7 + dx) & ok) | (ROWS & ~ok)) * CS + 8 * h;
+        }
+    }
+    half8 idf[2];   // identity A fragments: skip[cout][row] = sum_k I[cout][k] * x[k][row]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) idf[s][j] = (_Float16)((16 * s + 8 * h + j) == r32 ? 1.0f : 0.0f);
+
+    for (int L = 0; L < n_layers; ++L) {
+        const _Float16 *src = lds[L & 1];
+        _Float16 *dst = lds[(L & 1) ^ 1];
+        const bool second = L & 1;   // conv2 of a block: add the block input (lives in dst) and overwrite it
+        half8 w[KSTEPS];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) w[s] = wbuf[L & 1][s * 64 + lane];
+        float4 bias[4];
+        load_bias(nd.conv_b + L * F, bias);
+        prefetch(L + 1);
+        // Tile pipeline.  The epilogue of tile i-1 (VALU: LeakyReLU, fp16 convert, stores) is cut into
+        // 8 slices that are interleaved, in program order, between the MFMA pairs of tile i, so it
+        // issues in the gaps of the dependent chain instead of after it.
+        floatx16 pacc = {};
+        int prow = 0;
+        bool have_prev = false;
+        half4 pend;
+        auto epi_slice = [&](int sl) {   // accumulator elements 2sl, 2sl+1 of the previous tile
+            pend[2 * (sl & 1)] = (_Float16)lrelu(pacc[2 * sl]);
+            pend[2 * (sl & 1) + 1] = (_Float16)lrelu(pacc[2 * sl + 1]);
+            if (sl & 1) *reinterpret_cast<half4 *>(dst + prow + 8 * (sl >> 1) + 4 * h) = pend;
+        };
+#pragma unroll
+        for (int ti = 0; ti < TPW; ++ti) {
+            if (wave + ti * NWAVES < TILES) {
+                half8 bf[KSTEPS], xs[2];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) bf[s] = *reinterpret_cast<const half8 *>(src + rsel[ti][s >> 1] + (s & 1) * 16);
+                if (second) {
+                    xs[0] = *reinterpret_cast<const half8 *>(dst + rbase[ti] + 8 * h);
+                    xs[1] = *reinterpret_cast<const half8 *>(dst + rbase[ti] + 16 + 8 * h);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                floatx16 acc = acc_from_bias(bias);
+#pragma unroll
+                for (int k = 0; k < KSTEPS / 2; ++k) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[2 * k], bf[2 * k], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[2 * k + 1], bf[2 * k + 1], acc, 0, 0, 0);
+                    if (2 * k + 4 < KSTEPS) {
+                        bf[2 * k + 4] = *reinterpret_cast<const half8 *>(src + rsel[ti][k + 2]);
+                        bf[2 * k + 5] = *reinterpret_cast<const half8 *>(src + rsel[ti][k + 2] + 16);
+                    }
+                    if (have_prev && k < 8) epi_slice(k);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (second) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[0], xs[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[1], xs[1], acc, 0, 0, 0);
+                }
+                pacc = acc;
+                prow = rbase[ti];
+                have_prev = true;
+                // the other weight buffer has been idle since the previous layer's barrier: park the
+                // prefetched weights there as soon as the first tile is done (frees 12 VGPRs)
+                if (ti == 0) commit(L + 1);
+            }
+        }
+        store_tile(pacc, dst, prow, h);   // the wave's last tile has no chain to hide under
+        if (L < 6) stamp(3 + L);
+        __syncthreads();
+    }
+    stamp(9);
+    // tower output is in lds[0] (n_layers is even)
+
+    // ------------------------------------------------------------------ 1x1 head convs (value + 2 policy channels)
+    float *hs = reinterpret_cast<float *>(lds[1]);   // [P][HSTR] fp32: value plane 0..41, policy planes 42..125
+    {
+        const half8 w0 = nd.head_w[lane], w1 = nd.head_w[64 + lane];
+        const float hb0 = nd.head_b[0], hb1 = nd.head_b[1], hb2 = nd.head_b[2];
+        for (int t = wave; t < TILES; t += NWAVES) {
+            const int rg = t * 32 + r32;
+            const int p = rg / PIX, pix = rg - p * PIX;
+            const half8 a0 = *reinterpret_cast<const half8 *>(lds[0] + rg * CS + 8 * h);
+            const half8 a1 = *reinterpret_cast<const half8 *>(lds[0] + rg * CS + 16 + 8 * h);
+            floatx16 acc = {};
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, a0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, a1, acc, 0, 0, 0);
+            if (h == 0) {   // couts 0..3 sit in registers 0..3 of the lower half-wave
+                hs[p * HSTR + 0 * PIX + pix] = lrelu(acc[0] + hb0);
+                hs[p * HSTR + 1 * PIX + pix] = lrelu(acc[1] + hb1);
+                hs[p * HSTR + 2 * PIX + pix] = lrelu(acc[2] + hb2);
+            }
+        }
+        if (threadIdx.x < 2 * P) hs[(threadIdx.x >> 1) * HSTR + HEADV + (threadIdx.x & 1)] = 0.0f;   // pad 126,127
+    }
+    __syncthreads();
+    stamp(10);
+
+    // ------------------------------------------------------------------ MLP heads (fp32 VALU)
+    // wave w owns positions 2w and 2w+1.
+    //  value : lane o < 42 is one row of the collapsed Linear stack (model.py:69-70,83): 11 float4
+    //          table reads + 11 broadcast float4 reads of the value plane per position;
+    //  policy: lane = logit + 8*segment, each lane sums 11 of the 84 inputs (model.py:104,113),
+    //          segments are combined with three xor-shuffles.
+    {
+        const float *vt_b = reinterpret_cast<const float *>(mlp + VT_F4 + PT_F / 4);   // fc_b | vout_w | pfc_b
+        const float *pt = reinterpret_cast<const float *>(mlp + VT_F4);
+        const int pA = 2 * wave, pB = pA + 1;
+        const float4 *hA4 = reinterpret_cast<const float4 *>(hs + pA * HSTR);
+        const float4 *hB4 = reinterpret_cast<const float4 *>(hs + pB * HSTR);
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 11; ++g) {
+            const float4 wv = mlp[g * 64 + lane];
+            const float4 xa = hA4[g], xb = hB4[g];
+            a0 += wv.x * xa.x + wv.y * xa.y + wv.z * xa.z + wv.w * xa.w;
+            a1 += wv.x * xb.x + wv.y * xb.y + wv.z * xb.z + wv.w * xb.w;
+        }
+        const int seg = lane >> 3;
+        const float *hpA = hs + pA * HSTR + PIX + seg * 11, *hpB = hs + pB * HSTR + PIX + seg * 11;
+        float l0 = 0.0f, l1 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 11; ++c) {
+            const float wv = pt[c * 64 + lane];      // zero where seg*11 + c >= 84 or (lane & 7) == 7
+            l0 += wv * hpA[c];
+            l1 += wv * hpB[c];
+        }
+        // combine the 8 segments: lanes i and i^8 with a row rotate, the four 16-lane rows with two shuffles
+        l0 += dppf<0x128>(l0);
+        l1 += dppf<0x128>(l1);
+#pragma unroll
+        for (int m = 16; m <= 32; m <<= 1) {
+            l0 += __shfl_xor(l0, m, 64);
+            l1 += __shfl_xor(l1, m, 64);
+        }
+        const float fb = vt_b[lane], vw = vt_b[64 + lane], pb = vt_b[128 + lane];
+        const bool is_pol = lane < 7;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const float a = (pp ? a1 : a0) + fb;
+            const float lg = (pp ? l1 : l0) + pb;
+            const int gp = pos0 + (pp ? pB : pA);
+            const float rs = sum16(lane < PIX ? vw * lrelu(a) : 0.0f);               // model.py:83-85
+            const float vsum = readlane_f(rs, 0) + readlane_f(rs, 16) + readlane_f(rs, 32);
+            const float value = (tanhf(vsum + nd.vout_b) + nd.w1) * nd.w2;           // model.py:86-88
+            const float mx = max8(is_pol ? lg : -INFINITY);                          // lanes 0..7 hold the logits
+            const float e = is_pol ? expf(lg - mx) : 0.0f;
+            const float sum = sum8(e);
+            if (gp < n) {
+                if (lane == 0) values[gp] = value;
+                if (is_pol) priors[(size_t)gp * 7 + lane] = e / sum;
+            }
+        }
+    }
+    stamp(11);
+}
+
+}  // namespace c4net
+
+// host-side handle behind c4_net_* (include/c4_engine.h)
+struct c4_net {
+    int device;
+    c4net::NetDev d;
+    std::vector<void *> allocs;
+};

@@ -26,7 +26,8 @@ class SelfPlay:
     def __init__(self, net: Callable, n_slots: int, config: MCTSConfig, seed: int = 0, device: int = 0,
                  games_target: int = -1, record_capacity_games: int = 0, planes_dtype=torch.float32,
                  use_graph: bool = True, steps_per_graph: int = 8, max_inner_iters: int = 0,
-                 eval_cache_log2_entries: int = 0, level_budget: int = 0, pipeline: int = 1):
+                 eval_cache_log2_entries: int = 0, level_budget: int = 0, pipeline: int = 1,
+                 fused_loop: bool = False, steps_per_launch: int = 32):
         self.net = net
         self.n_slots = n_slots
         self.config = config
@@ -45,6 +46,9 @@ class SelfPlay:
         # (latency-bound) tree kernel of one half runs under the (MFMA-bound) network of the other
         self._pipeline = 2 if (pipeline == 2 and self._bits and n_slots % 16 == 0) else 1
         self._streams = None
+        # fused_loop: tree step + network in ONE persistent kernel (c4_selfplay_steps), no graph needed
+        self._fused_loop = bool(fused_loop and self._bits and n_slots % 16 == 0)
+        self._steps_per_launch = max(1, steps_per_launch)
         self._leaf_c0, self._leaf_c1, _ = self.engine.leaf_buffers()
         self.steps_done = 0
         self.steps_per_graph = max(1, steps_per_graph)
@@ -112,6 +116,18 @@ class SelfPlay:
 
     def run_steps(self, k: int):
         """Advance every slot by k rollout steps (asynchronous; call synchronize() to wait)."""
+        if self._fused_loop:
+            import ctypes as C
+            with torch.cuda.device(self.device):
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+                while k > 0:
+                    n = min(k, self._steps_per_launch)
+                    rc = self.engine._lib.c4_selfplay_steps(self.engine._h, self.net._h, C.c_void_p(self.values.data_ptr()),
+                                                            C.c_void_p(self.priors.data_ptr()), n, C.c_void_p(stream))
+                    L.check(rc, self.engine._h)
+                    k -= n
+                    self.steps_done += n
+            return
         with torch.cuda.device(self.device):
             if self._use_graph and self._graph is None and k >= self.steps_per_graph + 3:
                 self._capture()

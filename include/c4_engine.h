@@ -241,6 +241,14 @@ int c4_net_destroy(c4_net *net);
 int c4_net_forward(c4_net *net, void *hip_stream, const uint64_t *color0_dev, const uint64_t *color1_dev,
                    int32_t n, float *values_dev, float *priors_dev);
 const char *c4_net_last_error(void);
+
+/* Fused persistent self-play: n_steps rounds of {c4_step for 16 slots; c4_net_forward on their 16
+ * leaves} per workgroup in ONE launch -- no kernel boundary, no global barrier, a workgroup waits only
+ * for its own 16 trees.  Same results as alternating c4_step / c4_net_forward.  values_dev float32
+ * [n_slots], priors_dev float32 [n_slots][7] are the hand-off buffers (must persist between calls).
+ * Needs C4_EVAL_EXTERNAL_F32 and n_slots % 16 == 0. */
+int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *priors_dev, int32_t n_steps,
+                      void *hip_stream);
 /* diagnostic build aid: per-phase s_memtime stamps of workgroup 0, [8 waves][16]; needs the
  * environment variable C4_NET_STAMPS=1 when the net is created, else C4_ESTATE. */
 int c4_net_debug_stamps(c4_net *net, unsigned long long *out);

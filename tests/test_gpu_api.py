@@ -151,3 +151,30 @@ def test_match_lockstep_equals_sequential_oracle(oracle):
         draws += r == 0.5
         losses += r == 0.0
     assert (out["wins"], out["draws"], out["losses"]) == (wins, draws, losses)
+
+
+def test_fused_selfplay_kernel_equals_separate_kernels():
+    """c4_selfplay_steps (tree step + network in one persistent kernel) must play exactly the games
+    that alternating c4_step / c4_net_forward plays (same seed => same games, id by id)."""
+    from connect4_amd.config import MCTSConfig
+    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.net import random_init_state_dict
+    from connect4_amd.selfplay import SelfPlay
+    net = FusedNet(random_init_state_dict(seed=0))
+    cfg = MCTSConfig.self_play(48)
+    out = []
+    for fused in (False, True):
+        sp = SelfPlay(net, 64, cfg, seed=11, games_target=96, record_capacity_games=96, use_graph=False,
+                      fused_loop=fused, steps_per_launch=16, max_inner_iters=3)
+        for _ in range(400):
+            sp.run_steps(64)
+            if sp.stats()["active_slots"] == 0:
+                break
+        games = sorted(sp.drain(), key=lambda g: g.game_id)
+        st = sp.stats()
+        sp.close()
+        assert len(games) == 96
+        out.append(([(g.game_id, g.moves, g.result.value, g.values, [list(p) for p in g.priors]) for g in games], st))
+    assert out[0][0] == out[1][0]
+    for k in ("simulations", "expansions", "moves", "games_finished", "terminal_sims"):
+        assert out[0][1][k] == out[1][1][k]

@@ -91,6 +91,9 @@ def main():
                     help="2: two half-batches on two streams, tree kernel of one half under the net of the other")
     ap.add_argument("--fused-loop", type=int, default=1, help="1: tree step + net in one persistent kernel")
     ap.add_argument("--steps-per-launch", type=int, default=32)
+    ap.add_argument("--pmc-mode", action="store_true",
+                    help="for rocprofv3 --pmc passes: warm up with the fused kernel, then run the timed steps as "
+                         "separate eager launches (no HIP graph: PMC collection crashes inside graph replay)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=200, help="event-timed eager steps for the roofline")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -146,8 +149,12 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if args.pmc_mode:
+        sp._fused_loop, sp._use_graph = True, False
     sp.run_steps(args.warmup)
     sp.synchronize()
+    if args.pmc_mode:
+        sp._fused_loop = False
     s0 = sp.stats()
     barrier()
     torch.cuda.synchronize()
@@ -203,11 +210,26 @@ def main():
         ev_overhead_ms = sorted(a.elapsed_time(b) for a, b in cal)[len(cal) // 2]
         tree_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev) - ev_overhead_ms
         net_ms = sum(b.elapsed_time(c) for _, b, c in ev) / len(ev) - ev_overhead_ms
+        if args.net == "fused":
+            # the per-step pair also times the dispatch gap in front of this 160-KB-LDS kernel (it cannot
+            # start before the previous kernel has drained); its own duration is measured back to back
+            # on the leaves of the last step (same inputs every launch, outputs unchanged)
+            reps = 100
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record(stream)
+            for _ in range(reps):
+                sp.net.forward_bitboards(sp._leaf_c0, sp._leaf_c1, sp.n_slots, sp.values, sp.priors, stream.cuda_stream)
+            eb.record(stream)
+            torch.cuda.synchronize()
+            net_step_ms = net_ms
+            net_ms = (ea.elapsed_time(eb) - ev_overhead_ms) / reps
+        else:
+            net_step_ms = net_ms
         psims = p1["simulations"] - p0["simulations"]
         pdepth = (p1["depth_sum"] - p0["depth_sum"]) / max(1, psims)
         sims_per_launch = psims / len(ev)
         tree_bytes = tree_bytes_per_sim(pdepth) * sims_per_launch
-        prof = dict(tree_ms=tree_ms, net_ms=net_ms, ev_overhead_ms=ev_overhead_ms, sims_per_launch=sims_per_launch, mean_depth=pdepth,
+        prof = dict(tree_ms=tree_ms, net_ms=net_ms, net_step_ms=net_step_ms, ev_overhead_ms=ev_overhead_ms, sims_per_launch=sims_per_launch, mean_depth=pdepth,
                     tree_bytes_per_launch=tree_bytes)
 
     if rank == 0:
@@ -272,7 +294,7 @@ def main():
                 "kernel": ("c4_net_kernel (fused stem+tower+heads, v_mfma_f32_32x32x16_f16)" if args.net == "fused"
                            else "leaf-batch policy/value net forward (PyTorch-ROCm / MIOpen convs)"),
                 "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
-                "avg_forward_ms": prof["net_ms"],
+                "avg_forward_ms": prof["net_ms"], "avg_ms_in_step_incl_dispatch_gap": prof["net_step_ms"],
                 "traffic": ((pmc["FETCH_SIZE_net"] + pmc["WRITE_SIZE_net"]) * 1024.0
                             if pmc_ok and args.net == "fused" and "FETCH_SIZE_net" in pmc else None),
                 "positions_per_launch": args.slots, "leaves_needing_the_net_per_launch": net_leaves,

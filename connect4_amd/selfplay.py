@@ -25,7 +25,7 @@ class SelfPlay:
 
     def __init__(self, net: Callable, n_slots: int, config: MCTSConfig, seed: int = 0, device: int = 0,
                  games_target: int = -1, record_capacity_games: int = 0, planes_dtype=torch.float32,
-                 use_graph: bool = True, steps_per_graph: int = 8, max_inner_iters: int = 0,
+                 use_graph: bool = True, steps_per_graph: int = 8, max_inner_iters: int = 4,
                  eval_cache_log2_entries: int = 0, level_budget: int = 0, pipeline: int = 1,
                  fused_loop: bool = False, steps_per_launch: int = 32):
         self.net = net
@@ -165,7 +165,8 @@ def generate_games(config: MCTSConfig, net: Callable, n_games: int, n_slots: Opt
     TrainingLoop._generate_games hands to data_storage.save (training.py:131-135)."""
     n_slots = min(n_games, n_slots or 4096)
     sp = SelfPlay(net, n_slots, config, seed=seed, device=device, games_target=n_games,
-                  record_capacity_games=n_games, planes_dtype=planes_dtype, use_graph=use_graph)
+                  record_capacity_games=n_games, planes_dtype=planes_dtype, use_graph=use_graph,
+                  fused_loop=bool(getattr(net, "from_bitboards", False)))
     games: List[GameData] = []
     t0 = time.time()
     try:

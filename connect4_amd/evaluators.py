@@ -67,6 +67,9 @@ class DeviceNetEvaluator:
 
     def __call__(self, board: Board):
         import torch
+        if getattr(self.net, "from_bitboards", False):
+            v, p = self.net.evaluate_bits([board.color[0]], [board.color[1]])
+            return float(v[0]), p[0]
         x = torch.from_numpy(board.to_array().astype(np.float32)).unsqueeze(0).to("cuda:%d" % self.device)
         v, p = self.net(x)
         return float(v[0]), p[0].float().cpu().numpy()

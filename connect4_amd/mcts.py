@@ -104,14 +104,21 @@ class _Searcher:
         values = torch.zeros(G, dtype=torch.float32, device=dev)
         priors = torch.zeros(G, 7, dtype=torch.float32, device=dev)
         planes = torch.zeros(G, 3, 6, 7, dtype=torch.float32, device=dev)
-        eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-        eng.step(None, None, planes)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        eng.set_stream(stream)
+        net = self.dev_eval.net
+        bits = bool(getattr(net, "from_bitboards", False))   # fused kernel: evaluates the leaves' bitboards
+        c0p, c1p, _ = eng.leaf_buffers()
+        eng.step(None, None, None if bits else planes)
         steps = 0
         while True:
-            v, p = self.dev_eval.net(planes)
-            values.copy_(v)
-            priors.copy_(p)
-            eng.step(values, priors, planes)
+            if bits:
+                net.forward_bitboards(c0p, c1p, G, values, priors, stream)
+            else:
+                v, p = net(planes)
+                values.copy_(v)
+                priors.copy_(p)
+            eng.step(values, priors, None if bits else planes)
             steps += 1
             if steps % 64 == 0 and eng.stats()["active_slots"] == 0:
                 break

@@ -93,6 +93,17 @@ def test_device_net_search_and_generate_games():
         assert 0 <= move < 7 and b.age == 2
         assert tree.root.data.search_value.visit_count == 65
         assert abs(tree.get_values_policy().sum() - 1.0) < 1e-12
+    # the fused MFMA net behind the same player API
+    from connect4_amd.fused_net import FusedNet
+    fnet = FusedNet(random_init_state_dict(seed=0))
+    fboards = [Board() for _ in range(5)]
+    for b, mv in zip(fboards, (0, 3, 3, 6, 2)):
+        b.make_move(mv)
+    fouts = MCTS("fused", MCTSConfig(64), DeviceNetEvaluator(fnet)).make_moves(fboards)
+    for (move, value, tree) in fouts:
+        assert tree.root.data.search_value.visit_count == 65
+    v1, p1 = DeviceNetEvaluator(fnet)(Board())
+    assert 0.0 <= v1 <= 1.0 and abs(float(p1.sum()) - 1.0) < 1e-5
     games = generate_games(MCTSConfig.self_play(32), net, n_games=24, n_slots=16, seed=3)
     assert len(games) == 24 and sorted(g.game_id for g in games) == list(range(24))
     for g in games:
@@ -105,6 +116,10 @@ def test_device_net_search_and_generate_games():
     # determinism: same seed, same games (per game id)
     again = generate_games(MCTSConfig.self_play(32), net, n_games=24, n_slots=16, seed=3)
     assert [g.moves for g in again] == [g.moves for g in games]
+    fgames = generate_games(MCTSConfig.self_play(32), fnet, n_games=40, n_slots=32, seed=5)
+    assert len(fgames) == 40 and all(g.result is not None for g in fgames)
+    fagain = generate_games(MCTSConfig.self_play(32), fnet, n_games=40, n_slots=32, seed=5)
+    assert [g.moves for g in fagain] == [g.moves for g in fgames]
 
 
 def test_data_writer_matches_reference_native_to_pytorch():

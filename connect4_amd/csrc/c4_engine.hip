@@ -108,6 +108,32 @@ struct SlotStats {  // per-slot counters (summed on the host; no atomics => dete
 };
 constexpr int N_STATS = sizeof(SlotStats) / sizeof(uint64_t);
 
+// Rarely touched pointers (move choice, game end, suspended descents, diagnostics) live in device
+// memory behind one pointer: a kernel argument block with ~60 pointers does not fit the scalar
+// register file and the spills land in the descent loop.
+struct Cold {
+    uint32_t *cont_cur, *cont_n;   // a descent suspended by the level budget: current node, its N ...
+    double *cont_w;                // ... and W (its info lives in pending_info, the board in leaf_c0/1)
+    // per-slot result of the last chosen move
+    int32_t *res_move;
+    double *res_value;
+    double *res_policy;      // [G][7]
+    // RNG tapes (C4_RNG_TAPE)
+    const double *noise_tape;  // [tape_games][42][7]
+    const double *u_tape;      // [tape_games][42]
+    int tape_games;
+    // finished-game records, ring over game id
+    uint64_t *rec_c0, *rec_c1;   // [rec_cap][42]
+    int32_t *rec_move;
+    double *rec_value;
+    double *rec_policy;          // [rec_cap][42][7]
+    int32_t *game_len;           // [rec_cap] 0 = not finished
+    int32_t *game_result;
+    long long *game_tag;         // [rec_cap] id stored in the ring slot
+    unsigned long long *next_game;
+    unsigned long long *stamps;   // diagnostic (C4_TREE_STAMPS=1): [block][8] s_memtime values, first 256 blocks
+};
+
 struct Dev {
     // node pools: per slot `cap` records of 32 B (struct Rec), children in 8-aligned sibling blocks
     uint8_t *pool;
@@ -124,28 +150,11 @@ struct Dev {
     uint32_t *ply;
     long long *game_id;
     PathEntry *path;         // [G][MAX_DEPTH]
-    uint32_t *cont_cur, *cont_n;   // a descent suspended by the level budget: current node, its N ...
-    double *cont_w;                // ... and W (its info lives in pending_info, the board in leaf_c0/1)
     uint64_t *stats;         // [G][N_STATS]
-    // per-slot result of the last chosen move
-    int32_t *res_move;
-    double *res_value;
-    double *res_policy;      // [G][7]
     // score tables, index = parent visit count
     const double2 *tabAB;    // .x = log((n + base + 1)/base) + init (mcts.py:150-152), .y = sqrt(n) (mcts.py:156)
-    // RNG tapes (C4_RNG_TAPE)
-    const double *noise_tape;  // [tape_games][42][7]
-    const double *u_tape;      // [tape_games][42]
-    int tape_games;
-    // finished-game records, ring over game id
-    uint64_t *rec_c0, *rec_c1;   // [rec_cap][42]
-    int32_t *rec_move;
-    double *rec_value;
-    double *rec_policy;          // [rec_cap][42][7]
-    int32_t *game_len;           // [rec_cap] 0 = not finished
-    int32_t *game_result;
-    long long *game_tag;         // [rec_cap] id stored in the ring slot
-    unsigned long long *next_game;
+    CacheEntry *cache;       // evaluation cache (evaluators.py:18-25 memo table), direct mapped; null = off
+    const Cold *cold;
     // config
     int G;
     int slot_lo, slot_hi;    // slots advanced by this launch (c4_step_range; whole engine by default)
@@ -159,12 +168,11 @@ struct Dev {
     int level_budget;        // descent levels a slot may walk per launch (0 = unlimited)
     int planes_dtype;
     int rec_cap;
+    int cache_bits;
+    int has_stamps;          // diagnostic build aid enabled (C4_TREE_STAMPS=1)
     long long games_target;
     double alpha, frac;
     uint64_t seed;
-    CacheEntry *cache;     // evaluation cache (evaluators.py:18-25 memo table), direct mapped; null = off
-    int cache_bits;
-    unsigned long long *stamps;   // diagnostic (C4_TREE_STAMPS=1): [block][8] s_memtime values, first 256 blocks
 };
 
 // ------------------------------------------------------------------------------------------
@@ -429,7 +437,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
     }
 
     auto stamp = [&](int i) {
-        if (STAMPS && d.stamps && blockIdx.x < 256 && threadIdx.x == 0) d.stamps[blockIdx.x * 8 + i] = __builtin_amdgcn_s_memtime();
+        if (STAMPS && d.has_stamps && blockIdx.x < 256 && threadIdx.x == 0) d.cold->stamps[blockIdx.x * 8 + i] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -474,7 +482,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
             if (pdepth == 0 && d.use_noise) {
                 double nz = 0.0;
                 if (lane < 7) {
-                    if (d.rng_tape) nz = (gid < d.tape_games) ? d.noise_tape[((size_t)gid * 42 + ply) * 7 + lane] : 0.0;
+                    if (d.rng_tape) nz = (gid < d.cold->tape_games) ? d.cold->noise_tape[((size_t)gid * 42 + ply) * 7 + lane] : 0.0;
                     else nz = rng_gamma(d.seed, gid, ply, (uint32_t)lane, d.alpha);
                 }
                 if (!legal) nz = 0.0;
@@ -574,7 +582,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
             int kb = -1;
             double u = -1.0;
             if (root_age < d.nsm) {
-                if (d.rng_tape) u = (gid < d.tape_games) ? d.u_tape[(size_t)gid * 42 + ply] : -1.0;
+                if (d.rng_tape) u = (gid < d.cold->tape_games) ? d.cold->u_tape[(size_t)gid * 42 + ply] : -1.0;
                 else { double u1; rng_uniform2(d.seed, gid, ply, 32u, 0, u, u1); }
             }
             if (u >= 0.0) {   // tree.py:75-82 sample_value_fn(x**2) via np.random.choice's inverse-CDF
@@ -619,15 +627,15 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
             if (d.rec_cap > 0 && !d.stop_after_move) {
                 const size_t r = ((size_t)(gid % d.rec_cap)) * 42 + ply;
                 if (lane == 0) {
-                    d.rec_c0[r] = root0;
-                    d.rec_c1[r] = root1;
-                    d.rec_move[r] = mv;
-                    d.rec_value[r] = absv;
+                    d.cold->rec_c0[r] = root0;
+                    d.cold->rec_c1[r] = root1;
+                    d.cold->rec_move[r] = mv;
+                    d.cold->rec_value[r] = absv;
                 }
-                if (lane < 7) d.rec_policy[r * 7 + lane] = pol_col;
+                if (lane < 7) d.cold->rec_policy[r * 7 + lane] = pol_col;
             }
-            if (lane == 0) { d.res_move[g] = mv; d.res_value[g] = absv; }
-            if (lane < 7) d.res_policy[(size_t)g * 7 + lane] = pol_col;
+            if (lane == 0) { d.cold->res_move[g] = mv; d.cold->res_value[g] = absv; }
+            if (lane < 7) d.cold->res_policy[(size_t)g * 7 + lane] = pol_col;
             st.moves += 1;
             if (d.stop_after_move) {   // MCTS.make_move returns here; the tree stays readable
                 state = SLOT_MOVE_DONE;
@@ -638,14 +646,14 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
             if (bst >= ST_XWIN) {          // game over: training_game.py:17 game_data.result
                 if (d.rec_cap > 0 && lane == 0) {
                     const size_t r = (size_t)(gid % d.rec_cap);
-                    d.game_result[r] = (int32_t)(bst - ST_XWIN);
-                    d.game_tag[r] = gid;
+                    d.cold->game_result[r] = (int32_t)(bst - ST_XWIN);
+                    d.cold->game_tag[r] = gid;
                     __threadfence();
-                    d.game_len[r] = (int32_t)ply;
+                    d.cold->game_len[r] = (int32_t)ply;
                 }
                 st.games_finished += 1;
                 unsigned long long ng = 0;
-                if (lane == 0) ng = atomicAdd(d.next_game, 1ULL);
+                if (lane == 0) ng = atomicAdd(d.cold->next_game, 1ULL);
                 ng = ((unsigned long long)gshfl((uint32_t)(ng >> 32), 0) << 32) | gshfl((uint32_t)ng, 0);
                 if (d.games_target >= 0 && (long long)ng >= d.games_target) {
                     state = SLOT_PARKED;
@@ -656,7 +664,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
                 root0 = 0;
                 root1 = 0;
                 st.games_started += 1;
-                if (d.rec_cap > 0 && lane == 0) d.game_len[(size_t)(gid % d.rec_cap)] = 0;
+                if (d.rec_cap > 0 && lane == 0) d.cold->game_len[(size_t)(gid % d.rec_cap)] = 0;
             }
             need_root = 1;
             continue;
@@ -675,10 +683,10 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
         uint64_t b0, b1;
         if (resume) {            // pick a suspended descent up where the previous launch left it
             resume = false;
-            cur = d.cont_cur[g];
+            cur = d.cold->cont_cur[g];
             cinfo = pinfo;
-            cN = d.cont_n[g];
-            cW = d.cont_w[g];
+            cN = d.cold->cont_n[g];
+            cW = d.cold->cont_w[g];
             b0 = d.leaf_c0[g];
             b1 = d.leaf_c1[g];
             depth = pdepth;
@@ -694,7 +702,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
             if (lane == 0) s_path[gl][0] = PathEntry{0u, cN, cW};
         }
         int age = popc64(b0 | b1);
-        unsigned long long lvl_t0 = (STAMPS && d.stamps) ? __builtin_amdgcn_s_memtime() : 0, lvl_wait = 0, lvl_alu = 0, lvl_cnt = 0;
+        unsigned long long lvl_t0 = (STAMPS && d.has_stamps) ? __builtin_amdgcn_s_memtime() : 0, lvl_wait = 0, lvl_alu = 0, lvl_cnt = 0;
         while (info_status(cinfo) == ST_EVALUATED && levels_left > 0) {
             levels_left -= 1;
             const uint32_t cb = info_base(cinfo), nc = info_nchild(cinfo), pf64 = info_pf64(cinfo);
@@ -707,7 +715,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
             const double w = r.w, q = r.q, p = r.p;
             const double2 ab = d.tabAB[cN];
             const double A = ab.x, B = ab.y;
-            if (STAMPS && d.stamps) {   // diagnostic: cycles spent waiting for this level's loads
+            if (STAMPS && d.has_stamps) {   // diagnostic: cycles spent waiting for this level's loads
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime();
                 lvl_wait += t1 - lvl_t0;
@@ -729,24 +737,24 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
             age += 1;
             depth += 1;
             if (lane == 0) s_path[gl][depth] = PathEntry{cur, cN, cW};
-            if (STAMPS && d.stamps) {
+            if (STAMPS && d.has_stamps) {
                 const unsigned long long t2 = __builtin_amdgcn_s_memtime();
                 lvl_alu += t2 - lvl_t0;
                 lvl_t0 = t2;
                 lvl_cnt += 1;
             }
         }
-        if (STAMPS && d.stamps && blockIdx.x < 256 && threadIdx.x == 0) {
-            d.stamps[blockIdx.x * 8 + 7] = (lvl_wait << 32) | (lvl_alu & 0xffffffffu);
-            d.stamps[blockIdx.x * 8 + 6] = ((unsigned long long)lvl_cnt << 32) | depth;
+        if (STAMPS && d.has_stamps && blockIdx.x < 256 && threadIdx.x == 0) {
+            d.cold->stamps[blockIdx.x * 8 + 7] = (lvl_wait << 32) | (lvl_alu & 0xffffffffu);
+            d.cold->stamps[blockIdx.x * 8 + 6] = ((unsigned long long)lvl_cnt << 32) | depth;
         }
         if (info_status(cinfo) == ST_EVALUATED) {   // level budget exhausted mid-descent: suspend
             group_fence();
             for (uint32_t i = lane; i <= depth; i += GROUP) gpath[i] = s_path[gl][i];
             if (lane == 0) {
-                d.cont_cur[g] = cur;
-                d.cont_n[g] = cN;
-                d.cont_w[g] = cW;
+                d.cold->cont_cur[g] = cur;
+                d.cold->cont_n[g] = cN;
+                d.cold->cont_w[g] = cW;
                 d.leaf_c0[g] = b0;
                 d.leaf_c1[g] = b1;
             }
@@ -883,11 +891,11 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
     const int sl = wv + NWAVES * grp;     // slot of this 8-lane group inside the workgroup (grp < 2)
     unsigned long long t_tree = 0, t_net = 0, t_own = 0;   // diagnostic (C4_TREE_STAMPS=1)
     for (int step = 0; step < n_steps; ++step) {
-        const unsigned long long ta = d.stamps ? __builtin_amdgcn_s_memtime() : 0;
+        const unsigned long long ta = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
         if (grp < P / NWAVES) tree_step<C4_EVAL_EXTERNAL_F32, false>(d, slot0 + sl, lane, sl, s_path, values, priors, nullptr, nullptr);
-        const unsigned long long tb = d.stamps ? __builtin_amdgcn_s_memtime() : 0;
+        const unsigned long long tb = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
         __syncthreads();   // tree-phase global stores (leaf boards, node records) are visible to the whole CU
-        const unsigned long long tc = d.stamps ? __builtin_amdgcn_s_memtime() : 0;
+        const unsigned long long tc = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
         t_own += tb - ta;
         t_tree += tc - ta;
         if (threadIdx.x < 2 * P) {
@@ -898,10 +906,10 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
         net_forward_block(nd, NetLds{act, wbuf, mlp}, sleaf[0], sleaf[1], min(P, d.G - slot0), 0, values + slot0,
                           priors + (size_t)slot0 * 7);
         __syncthreads();   // values/priors written; LDS free for the next tree phase
-        if (d.stamps) t_net += __builtin_amdgcn_s_memtime() - tc;
+        if (d.has_stamps) t_net += __builtin_amdgcn_s_memtime() - tc;
     }
-    if (d.stamps && blockIdx.x < 256 && (threadIdx.x & 63) == 0) {
-        unsigned long long *o = d.stamps + blockIdx.x * 8;
+    if (d.has_stamps && blockIdx.x < 256 && (threadIdx.x & 63) == 0) {
+        unsigned long long *o = d.cold->stamps + blockIdx.x * 8;
         if (wv == 0) { o[0] = t_tree; o[1] = t_net; o[2] = (unsigned long long)n_steps; }
         if (wv < 5) o[3 + wv] = t_own;   // this wave's own tree work (waves 0..4)
     }
@@ -929,14 +937,14 @@ __global__ void c4_reset_kernel(Dev d, const uint64_t *c0, const uint64_t *c1, i
     d.need_root[g] = active ? 1 : 0;
     d.ply[g] = 0;
     d.game_id[g] = g;
-    d.res_move[g] = -1;
-    d.res_value[g] = 0.0;
-    for (int i = 0; i < 7; ++i) d.res_policy[(size_t)g * 7 + i] = 0.0;
+    d.cold->res_move[g] = -1;
+    d.cold->res_value[g] = 0.0;
+    for (int i = 0; i < 7; ++i) d.cold->res_policy[(size_t)g * 7 + i] = 0.0;
     uint64_t *sp = d.stats + (size_t)g * N_STATS;
     for (int i = 0; i < N_STATS; ++i) sp[i] = 0;
     if (active) sp[offsetof(SlotStats, games_started) / 8] = 1;
-    if (g == 0) *d.next_game = (unsigned long long)n_active;
-    for (int r = g; r < d.rec_cap; r += d.G) { d.game_len[r] = 0; d.game_result[r] = -1; d.game_tag[r] = -1; }
+    if (g == 0) *d.cold->next_game = (unsigned long long)n_active;
+    for (int r = g; r < d.rec_cap; r += d.G) { d.cold->game_len[r] = 0; d.cold->game_result[r] = -1; d.cold->game_tag[r] = -1; }
 }
 
 __global__ void c4_gather_roots_kernel(Dev d, c4_root_result *out)
@@ -947,12 +955,12 @@ __global__ void c4_gather_roots_kernel(Dev d, c4_root_result *out)
     memset(&r, 0, sizeof(r));
     const Pool pool{d.pool + (size_t)g * d.cap * (BLOCK_BYTES / 8)};
     r.state = d.state[g];
-    r.move = d.res_move[g];
-    r.value = d.res_value[g];
+    r.move = d.cold->res_move[g];
+    r.value = d.cold->res_value[g];
     r.color0 = d.root_c0[g];
     r.color1 = d.root_c1[g];
     const uint32_t rinfo = pool.info(0);
-    for (int i = 0; i < 7; ++i) { r.child_status[i] = -2; r.values_policy[i] = d.res_policy[(size_t)g * 7 + i]; }
+    for (int i = 0; i < 7; ++i) { r.child_status[i] = -2; r.values_policy[i] = d.cold->res_policy[(size_t)g * 7 + i]; }
     if (info_status(rinfo) == ST_EVALUATED) {
         r.root_visits = pool.n(0);
         r.root_value_sum = pool.w(0);
@@ -1034,6 +1042,8 @@ struct c4_engine {
     int device;
     hipStream_t stream;
     Dev d;
+    Cold cold;        // host copy of *d.cold
+    Cold *cold_dev;
     std::vector<void *> allocs;
     std::vector<long long> drained_tag;   // per ring slot: game id already handed out (-1 none)
     int64_t launches;
@@ -1053,6 +1063,13 @@ struct c4_engine {
     } while (0)
 
 namespace {
+
+int sync_cold(c4_engine *e)
+{
+    hipError_t r = hipMemcpy(e->cold_dev, &e->cold, sizeof(Cold), hipMemcpyHostToDevice);
+    if (r != hipSuccess) { set_err(e->err, "cold-state upload failed: %s", hipGetErrorString(r)); return C4_EDEVICE; }
+    return C4_OK;
+}
 
 template <typename T>
 int dev_alloc(c4_engine *e, T **p, size_t count)
@@ -1115,9 +1132,9 @@ int c4_abi_version(void) { return C4_ABI_VERSION; }
 /* diagnostic: s_memtime stamps of the last launch, [256 blocks][8] (needs C4_TREE_STAMPS=1 at create) */
 int c4_debug_stamps(c4_engine *e, unsigned long long *out)
 {
-    if (!e || !out || !e->d.stamps) return C4_ESTATE;
+    if (!e || !out || !e->cold.stamps) return C4_ESTATE;
     if (hipStreamSynchronize(e->stream) != hipSuccess) return C4_EDEVICE;
-    return hipMemcpy(out, e->d.stamps, 256 * 8 * 8, hipMemcpyDeviceToHost) == hipSuccess ? C4_OK : C4_EDEVICE;
+    return hipMemcpy(out, e->cold.stamps, 256 * 8 * 8, hipMemcpyDeviceToHost) == hipSuccess ? C4_OK : C4_EDEVICE;
 }
 
 const char *c4_last_error(const c4_engine *e) { return e ? e->err : g_err; }
@@ -1145,6 +1162,8 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     e->tape_u = nullptr;
     e->err[0] = 0;
     memset(&e->d, 0, sizeof(Dev));
+    memset(&e->cold, 0, sizeof(Cold));
+    e->cold_dev = nullptr;
     Dev &d = e->d;
     const size_t G = (size_t)cfg->n_slots;
     d.G = cfg->n_slots;
@@ -1178,14 +1197,14 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     ALLOC(d.sims_done, G); ALLOC(d.n_alloc, G); ALLOC(d.state, G); ALLOC(d.need_root, G);
     ALLOC(d.ply, G); ALLOC(d.game_id, G);
     ALLOC(d.path, G * MAX_DEPTH);
-    ALLOC(d.cont_cur, G); ALLOC(d.cont_n, G); ALLOC(d.cont_w, G);
+    ALLOC(e->cold.cont_cur, G); ALLOC(e->cold.cont_n, G); ALLOC(e->cold.cont_w, G);
     ALLOC(d.stats, G * N_STATS);
-    ALLOC(d.res_move, G); ALLOC(d.res_value, G); ALLOC(d.res_policy, G * 7);
-    ALLOC(d.next_game, 1);
+    ALLOC(e->cold.res_move, G); ALLOC(e->cold.res_value, G); ALLOC(e->cold.res_policy, G * 7);
+    ALLOC(e->cold.next_game, 1);
     const size_t R = (size_t)d.rec_cap;
-    ALLOC(d.rec_c0, R * 42); ALLOC(d.rec_c1, R * 42); ALLOC(d.rec_move, R * 42);
-    ALLOC(d.rec_value, R * 42); ALLOC(d.rec_policy, R * 42 * 7);
-    ALLOC(d.game_len, R); ALLOC(d.game_result, R); ALLOC(d.game_tag, R);
+    ALLOC(e->cold.rec_c0, R * 42); ALLOC(e->cold.rec_c1, R * 42); ALLOC(e->cold.rec_move, R * 42);
+    ALLOC(e->cold.rec_value, R * 42); ALLOC(e->cold.rec_policy, R * 42 * 7);
+    ALLOC(e->cold.game_len, R); ALLOC(e->cold.game_result, R); ALLOC(e->cold.game_tag, R);
     // score tables (host libm so that log() is the very function Python's math.log calls)
     {
         const size_t nt = (size_t)cfg->simulations + 4;
@@ -1199,7 +1218,6 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
         if (hipMemcpy(tAB, AB.data(), nt * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess) { set_err(g_err, "table upload failed"); c4_engine_destroy(e); return C4_EDEVICE; }
         d.tabAB = tAB;
     }
-#undef ALLOC
     e->drained_tag.assign(R, -1);
     {   // evaluation cache: <0 off, 0 auto (self-play with a float32 evaluator only), else log2(entries)
         int bits = cfg->eval_cache_log2_entries;
@@ -1219,8 +1237,13 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     }
     if (getenv("C4_TREE_STAMPS")) {
         unsigned long long *q = nullptr;
-        if (dev_alloc(e, &q, 256 * 8) == C4_OK) { (void)hipMemset(q, 0, 256 * 8 * 8); d.stamps = q; }
+        if (dev_alloc(e, &q, 256 * 8) == C4_OK) { (void)hipMemset(q, 0, 256 * 8 * 8); e->cold.stamps = q; }
     }
+    d.has_stamps = e->cold.stamps != nullptr;
+    ALLOC(e->cold_dev, 1);
+#undef ALLOC
+    d.cold = e->cold_dev;
+    if ((rc = sync_cold(e)) != C4_OK) { strncpy(g_err, e->err, 511); c4_engine_destroy(e); return rc; }
     *out = e;
     rc = c4_reset(e, nullptr, nullptr, cfg->n_slots);
     if (rc) { strncpy(g_err, e->err, 511); c4_engine_destroy(e); *out = nullptr; return rc; }
@@ -1299,10 +1322,10 @@ int c4_set_tapes(c4_engine *e, const double *gamma_noise, const double *uniforms
     HIPCHK(e, hipMalloc((void **)&e->tape_u, sizeof(double) * 42 * (size_t)n_games));
     HIPCHK(e, hipMemcpy(e->tape_noise, gamma_noise, sizeof(double) * 42 * 7 * (size_t)n_games, hipMemcpyHostToDevice));
     HIPCHK(e, hipMemcpy(e->tape_u, uniforms, sizeof(double) * 42 * (size_t)n_games, hipMemcpyHostToDevice));
-    e->d.noise_tape = e->tape_noise;
-    e->d.u_tape = e->tape_u;
-    e->d.tape_games = n_games;
-    return C4_OK;
+    e->cold.noise_tape = e->tape_noise;
+    e->cold.u_tape = e->tape_u;
+    e->cold.tape_games = n_games;
+    return sync_cold(e);
 }
 
 int c4_step_range(c4_engine *e, const void *values_dev, const void *priors_dev, void *planes_dev, int32_t slot_lo,
@@ -1310,7 +1333,7 @@ int c4_step_range(c4_engine *e, const void *values_dev, const void *priors_dev, 
 {
     if (!e) return C4_EINVAL;
     if (slot_lo < 0 || slot_count <= 0 || slot_lo + slot_count > e->d.G || (slot_lo % SLOTS_PER_BLOCK)) { set_err(e->err, "c4_step_range: bad slot range [%d,+%d) (start must be a multiple of %d)", slot_lo, slot_count, SLOTS_PER_BLOCK); return C4_EINVAL; }
-    if (e->d.rng_tape && (e->d.use_noise || e->d.nsm > 0) && !e->d.noise_tape) { set_err(e->err, "C4_RNG_TAPE engine needs c4_set_tapes before stepping"); return C4_ESTATE; }
+    if (e->d.rng_tape && (e->d.use_noise || e->d.nsm > 0) && !e->cold.noise_tape) { set_err(e->err, "C4_RNG_TAPE engine needs c4_set_tapes before stepping"); return C4_ESTATE; }
     if (e->cfg.eval_mode != C4_EVAL_CENTRE && e->launches > 0 && (!values_dev || !priors_dev)) { set_err(e->err, "c4_step: values/priors are required after the first step"); return C4_EINVAL; }
     Dev d = e->d;
     d.slot_lo = slot_lo;
@@ -1339,7 +1362,7 @@ int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *prior
     if (e->cfg.eval_mode != C4_EVAL_EXTERNAL_F32) { set_err(e->err, "c4_selfplay_steps needs C4_EVAL_EXTERNAL_F32"); return C4_ESTATE; }
     if (e->d.G % c4net::P) { set_err(e->err, "c4_selfplay_steps needs n_slots to be a multiple of %d", c4net::P); return C4_EINVAL; }
     if (net->device != e->device) { set_err(e->err, "engine and net live on different devices"); return C4_EINVAL; }
-    if (e->d.rng_tape && (e->d.use_noise || e->d.nsm > 0) && !e->d.noise_tape) { set_err(e->err, "C4_RNG_TAPE engine needs c4_set_tapes before stepping"); return C4_ESTATE; }
+    if (e->d.rng_tape && (e->d.use_noise || e->d.nsm > 0) && !e->cold.noise_tape) { set_err(e->err, "C4_RNG_TAPE engine needs c4_set_tapes before stepping"); return C4_ESTATE; }
     c4net::NetDev nd = net->d;
     nd.stamps = nullptr;
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
@@ -1449,9 +1472,9 @@ int c4_drain_games(c4_engine *e, c4_game_record *out, int32_t cap, int32_t *n_ou
     HIPCHK(e, hipStreamSynchronize(e->stream));
     std::vector<int32_t> len(R), res(R);
     std::vector<long long> tag(R);
-    HIPCHK(e, hipMemcpy(len.data(), e->d.game_len, R * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIPCHK(e, hipMemcpy(res.data(), e->d.game_result, R * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIPCHK(e, hipMemcpy(tag.data(), e->d.game_tag, R * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(len.data(), e->cold.game_len, R * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(res.data(), e->cold.game_result, R * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(tag.data(), e->cold.game_tag, R * sizeof(long long), hipMemcpyDeviceToHost));
     // finished + not yet drained, by game id
     std::vector<std::pair<long long, size_t>> ready;
     for (size_t r = 0; r < R; ++r)
@@ -1464,11 +1487,11 @@ int c4_drain_games(c4_engine *e, c4_game_record *out, int32_t cap, int32_t *n_ou
     for (auto &pr : ready) {
         if (n >= cap) break;
         const size_t r = pr.second;
-        HIPCHK(e, hipMemcpy(b0.data(), e->d.rec_c0 + r * 42, 42 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        HIPCHK(e, hipMemcpy(b1.data(), e->d.rec_c1 + r * 42, 42 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        HIPCHK(e, hipMemcpy(mv.data(), e->d.rec_move + r * 42, 42 * sizeof(int32_t), hipMemcpyDeviceToHost));
-        HIPCHK(e, hipMemcpy(val.data(), e->d.rec_value + r * 42, 42 * sizeof(double), hipMemcpyDeviceToHost));
-        HIPCHK(e, hipMemcpy(pol.data(), e->d.rec_policy + r * 42 * 7, 42 * 7 * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(b0.data(), e->cold.rec_c0 + r * 42, 42 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(b1.data(), e->cold.rec_c1 + r * 42, 42 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(mv.data(), e->cold.rec_move + r * 42, 42 * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(val.data(), e->cold.rec_value + r * 42, 42 * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(pol.data(), e->cold.rec_policy + r * 42 * 7, 42 * 7 * sizeof(double), hipMemcpyDeviceToHost));
         c4_game_record &g = out[n];
         memset(&g, 0, sizeof(g));
         g.game_id = pr.first;

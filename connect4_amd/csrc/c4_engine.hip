@@ -385,7 +385,8 @@ template <> __device__ __forceinline__ void store_plane<hip_bfloat16>(void *p, s
 // the emitted leaf's bitboards {color0, color1} or {0,0} when the slot emits nothing.
 template <int EVAL, bool STAMPS = true>
 __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int lane, const int gl,
-                                          PathEntry (*s_path)[MAX_DEPTH], const void *__restrict__ values_in,
+                                          PathEntry (*s_path)[MAX_DEPTH], Rec (*s_l1)[GROUP],
+                                          const void *__restrict__ values_in,
                                           const void *__restrict__ priors_in, void *__restrict__ planes_out,
                                           uint64_t *leaf_out)
 {
@@ -447,6 +448,10 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
     // does about the same amount of work per launch instead of waiting for the deepest tree.
     int levels_left = d.level_budget > 0 ? d.level_budget : 0x7fffffff;
     bool resume = (pend == -2);
+    // Hot subtree in LDS: once a launch has loaded the root's sibling block it stays in s_l1 for all
+    // further simulations of the launch (write-through on every backup), so level 1 of every later
+    // descent is an LDS read instead of an HBM round trip.
+    bool l1_valid = false;
     int inner = 0;
     for (;;) {
         // ---------------------------------------------------------------- evaluate_node + expand + backup
@@ -509,6 +514,13 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
                 *pool.rec(idx) = Rec{0.0, 0.0, prn, 0u, pack_info(0, 0, cst, bit, 0)};
             }
             if (lane == 0) {   // mcts.py:132-134: position_value / search_value.add(value)
+                if (l1_valid && pdepth == 1) {   // the leaf is a child of the root: keep the LDS copy current
+                    Rec &c = s_l1[gl][pend & 7];
+                    c.n = 1;
+                    c.w = ev_value;
+                    c.q = ev_value;
+                    c.info = pack_info(base, nchild, ST_EVALUATED, info_bit(pinfo), pf64);
+                }
                 pool.n(pend) = 1;
                 pool.w(pend) = ev_value;
                 pool.q(pend) = ev_value;
@@ -517,11 +529,13 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
             // mcts.py:164-168 backpropagate over the ancestors (values captured during the descent)
             for (uint32_t i = lane; i < pdepth; i += GROUP) {
                 const PathEntry e = path_lds ? s_path[gl][i] : gpath[i];
-                const double nw = e.w + ev_value;
+                const double nw = e.w + ev_value, nq = nw / (double)(e.n + 1);
                 pool.n(e.node) = e.n + 1;
                 pool.w(e.node) = nw;
-                pool.q(e.node) = nw / (double)(e.n + 1);
+                pool.q(e.node) = nq;
+                if (l1_valid && i == 1) { Rec &c = s_l1[gl][e.node & 7]; c.n = e.n + 1; c.w = nw; c.q = nq; }
             }
+            if (pdepth == 0) l1_valid = false;   // a new sibling block under the root
             st.leaf_evals += 1;
             st.children += nchild;
             if (pdepth > 0) sims += 1;
@@ -534,6 +548,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
         // ---------------------------------------------------------------- new root (Tree(board), tree.py:62-64)
         if (need_root) {
             need_root = 0;
+            l1_valid = false;
             nalloc = 1;
             sims = 0;
             pend = 0;
@@ -710,7 +725,15 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
             const bool act = lane < (int)nc;
             const uint32_t idx = cb + lane;
             Rec r = {};
-            if (act) r = *pool.rec(idx);                      // two 16-byte loads per lane
+            if (depth == 0 && l1_valid) {
+                if (act) r = s_l1[gl][lane];                  // hot subtree: LDS
+            } else {
+                if (act) r = *pool.rec(idx);                  // two 16-byte loads per lane
+                if (depth == 0) {                             // first descent of the launch: stage the block
+                    if (act) s_l1[gl][lane] = r;
+                    l1_valid = true;
+                }
+            }
             const uint32_t n = r.n, inf = r.info;
             const double w = r.w, q = r.q, p = r.p;
             const double2 ab = d.tabAB[cN];
@@ -772,10 +795,11 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
             group_fence();   // s_path written by lane 0
             for (uint32_t i = lane; i <= depth; i += GROUP) {
                 const PathEntry e = s_path[gl][i];
-                const double nw = e.w + value;
+                const double nw = e.w + value, nq = nw / (double)(e.n + 1);
                 pool.n(e.node) = e.n + 1;
                 pool.w(e.node) = nw;
-                pool.q(e.node) = nw / (double)(e.n + 1);
+                pool.q(e.node) = nq;
+                if (l1_valid && i == 1) { Rec &c = s_l1[gl][e.node & 7]; c.n = e.n + 1; c.w = nw; c.q = nq; }
             }
             sims += 1;
             st.sims += 1;
@@ -859,10 +883,11 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
                                                         void *__restrict__ planes_out)
 {
     __shared__ PathEntry s_path[SLOTS_PER_BLOCK][MAX_DEPTH];
+    __shared__ Rec s_l1[SLOTS_PER_BLOCK][GROUP];   // hot subtree: the root's sibling block, LDS-resident for the launch
     const int lane = threadIdx.x & (GROUP - 1);
     const int gl = threadIdx.x / GROUP;
     const int g = d.slot_lo + blockIdx.x * SLOTS_PER_BLOCK + gl;
-    tree_step<EVAL>(d, g, lane, gl, s_path, values_in, priors_in, planes_out, nullptr);
+    tree_step<EVAL>(d, g, lane, gl, s_path, s_l1, values_in, priors_in, planes_out, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -880,9 +905,10 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
     __shared__ __attribute__((aligned(16))) half8 wbuf[2][WCHUNKS];
     __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
     __shared__ uint64_t sleaf[2][P];   // leaf bitboards handed from the tree phase to the net phase
-    static_assert(sizeof(PathEntry) * MAX_DEPTH * P <= sizeof(_Float16) * ROWS * CS, "path stack must fit the activation buffer");
+    static_assert((sizeof(PathEntry) * MAX_DEPTH + sizeof(Rec) * GROUP) * P <= sizeof(_Float16) * ROWS * CS, "tree-phase LDS must fit the activation buffer");
     // the tree phase's path stacks live in activation buffer 0, which the net overwrites afterwards
     PathEntry (*s_path)[MAX_DEPTH] = reinterpret_cast<PathEntry (*)[MAX_DEPTH]>(&act[0][0]);
+    Rec (*s_l1)[GROUP] = reinterpret_cast<Rec (*)[GROUP]>(&act[0][0] + sizeof(PathEntry) * MAX_DEPTH * P / sizeof(_Float16));
     const int slot0 = blockIdx.x * P;
     const int lane = threadIdx.x & (GROUP - 1);
     // two slots per wave (lanes 0..15), all 8 waves busy: slots that sit in one wave execute in SIMT
@@ -892,7 +918,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
     unsigned long long t_tree = 0, t_net = 0, t_own = 0;   // diagnostic (C4_TREE_STAMPS=1)
     for (int step = 0; step < n_steps; ++step) {
         const unsigned long long ta = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
-        if (grp < P / NWAVES) tree_step<C4_EVAL_EXTERNAL_F32, false>(d, slot0 + sl, lane, sl, s_path, values, priors, nullptr, nullptr);
+        if (grp < P / NWAVES) tree_step<C4_EVAL_EXTERNAL_F32, false>(d, slot0 + sl, lane, sl, s_path, s_l1, values, priors, nullptr, nullptr);
         const unsigned long long tb = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
         __syncthreads();   // tree-phase global stores (leaf boards, node records) are visible to the whole CU
         const unsigned long long tc = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;

@@ -185,6 +185,10 @@ __device__ __forceinline__ uint32_t gshfl(uint32_t v, int src) { return (uint32_
 
 // Orders this wave's global + LDS stores before its later loads (lanes of a group communicate
 // through memory inside one wave).  Workgroup scope = the same CU's L1, which is what we need.
+// LDS-only variant: lane 0 wrote the path stack, other lanes of the same wave read it next.  LDS
+// operations of a wave execute in order; this only has to stop the compiler and drain lgkmcnt.
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ void group_fence()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -772,7 +776,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
             d.cold->stamps[blockIdx.x * 8 + 6] = ((unsigned long long)lvl_cnt << 32) | depth;
         }
         if (info_status(cinfo) == ST_EVALUATED) {   // level budget exhausted mid-descent: suspend
-            group_fence();
+            lds_fence();
             for (uint32_t i = lane; i <= depth; i += GROUP) gpath[i] = s_path[gl][i];
             if (lane == 0) {
                 d.cold->cont_cur[g] = cur;
@@ -792,7 +796,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
         if (lst >= ST_XWIN) {
             // mcts.py:125-128,134 + :164-168: terminal leaf, exact result, no evaluator
             const double value = 0.5 * (double)(lst - ST_XWIN);
-            group_fence();   // s_path written by lane 0
+            lds_fence();   // s_path written by lane 0
             for (uint32_t i = lane; i <= depth; i += GROUP) {
                 const PathEntry e = s_path[gl][i];
                 const double nw = e.w + value, nq = nw / (double)(e.n + 1);
@@ -817,11 +821,11 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
         if (EVAL == C4_EVAL_CENTRE) {
             ev_value = centre_value(b0, b1);
             ev_prior = 1.0 / 7.0;
-            group_fence();   // s_path -> read by the apply above
+            lds_fence();   // s_path -> read by the apply above
             apply_now = true;
             continue;
         }
-        group_fence();
+        lds_fence();
         if (EVAL == C4_EVAL_EXTERNAL_F32 && d.cache) {   // evaluators.py:19-20 position_table.get
             float cv, cp;
             st.cache_probes += 1;

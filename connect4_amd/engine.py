@@ -149,18 +149,6 @@ class Engine:
 
 
 # -- pure board functions executed by the device code ------------------------------------------
-def _run_board(fn_name, device, inputs, outputs):
-    lib = L.load()
-    args = [device]
-    for a, ct in inputs:
-        args.append(_ptr(a, ct))
-    n = len(inputs[0][0])
-    args.append(n)
-    for a, ct in outputs:
-        args.append(_ptr(a, ct))
-    L.check(getattr(lib, fn_name)(*args))
-
-
 def board_make_move(color0, color1, cols, device=0):
     c0, c1 = _u64(color0), _u64(color1)
     col = np.ascontiguousarray(cols, dtype=np.int32)

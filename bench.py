@@ -84,9 +84,10 @@ def main():
                     help="fused: hand-written gfx950 MFMA kernel (fp16 storage, fp32 accumulate); torch: PyTorch-ROCm/MIOpen")
     ap.add_argument("--net-dtype", default=None, choices=["f32", "f16", "bf16"], help="torch net only (default f32)")
     ap.add_argument("--steps-per-graph", type=int, default=8)
-    ap.add_argument("--max-inner", type=int, default=4, help="evaluator-free simulations a slot may run per launch (0 = engine default)")
+    ap.add_argument("--max-inner", type=int, default=32, help="evaluator-free simulations a slot may run per launch (0 = engine default)")
     ap.add_argument("--eval-cache", type=int, default=0, help="log2 entries of the evaluation cache (0 auto, -1 off)")
     ap.add_argument("--level-budget", type=int, default=0, help="descent levels per slot per launch (0 unlimited)")
+    ap.add_argument("--time-budget", type=int, default=80000, help="shader cycles per step call after which a slot starts no new simulation")
     ap.add_argument("--pipeline", type=int, default=1, choices=[1, 2],
                     help="2: two half-batches on two streams, tree kernel of one half under the net of the other")
     ap.add_argument("--fused-loop", type=int, default=1, help="1: tree step + net in one persistent kernel")
@@ -142,7 +143,7 @@ def main():
     sp = SelfPlay(net, args.slots, MCTSConfig.self_play(args.sims), seed=rank, device=local_rank,
                   games_target=-1, record_capacity_games=2 * args.slots, planes_dtype=tdt,
                   use_graph=not args.no_graph, steps_per_graph=args.steps_per_graph, max_inner_iters=args.max_inner,
-                  eval_cache_log2_entries=args.eval_cache, level_budget=args.level_budget, pipeline=args.pipeline,
+                  eval_cache_log2_entries=args.eval_cache, level_budget=args.level_budget, time_budget_cycles=args.time_budget, pipeline=args.pipeline,
                   fused_loop=bool(args.fused_loop), steps_per_launch=args.steps_per_launch)
 
     def barrier():
@@ -261,7 +262,7 @@ def main():
                 "slots_per_gpu": args.slots, "simulations": args.sims, "net": "32f-3res-4fc",
                 "net_impl": args.net, "net_dtype": args.net_dtype, "tree_dtype": "u64 bitboards, u32 visits, f64 value sums/priors",
                 "parallelism": "games sharded over %d GPU(s), no collective in the rollout path" % world,
-                "max_inner_iters": args.max_inner, "eval_cache_log2_entries": args.eval_cache, "level_budget": args.level_budget, "pipeline_halves": args.pipeline, "fused_loop": bool(args.fused_loop), "steps_per_launch": args.steps_per_launch, "hip_graph": (not args.no_graph), "steps_per_graph": args.steps_per_graph,
+                "max_inner_iters": args.max_inner, "eval_cache_log2_entries": args.eval_cache, "level_budget": args.level_budget, "time_budget_cycles": args.time_budget, "pipeline_halves": args.pipeline, "fused_loop": bool(args.fused_loop), "steps_per_launch": args.steps_per_launch, "hip_graph": (not args.no_graph), "steps_per_graph": args.steps_per_graph,
                 "dirichlet_alpha": 0.3, "exploration_fraction": 0.25, "num_sampling_moves": 6,
             },
         }

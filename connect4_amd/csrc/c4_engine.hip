@@ -166,6 +166,7 @@ struct Dev {
     int stop_after_move;
     int max_inner;
     int level_budget;        // descent levels a slot may walk per launch (0 = unlimited)
+    int time_budget;         // shader cycles after which a slot starts no new simulation in this call (0 = off)
     int planes_dtype;
     int rec_cap;
     int cache_bits;
@@ -451,6 +452,10 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
     // suspended (node, board and path are saved) and resumed by the next launch.  Every wave then
     // does about the same amount of work per launch instead of waiting for the deepest tree.
     int levels_left = d.level_budget > 0 ? d.level_budget : 0x7fffffff;
+    // time budget: a slot starts no further evaluator-free simulation once the call has run this many
+    // shader cycles, so cheap (shallow / terminal / cached) simulations are not rationed by count and
+    // every wave of a launch ends at about the same time
+    const unsigned long long t_begin = d.time_budget > 0 ? __builtin_amdgcn_s_memtime() : 0;
     bool resume = (pend == -2);
     // Hot subtree in LDS: once a launch has loaded the root's sibling block it stays in s_l1 for all
     // further simulations of the launch (write-through on every backup), so level 1 of every later
@@ -690,7 +695,8 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
         }
 
         // bound the launch: at most max_inner evaluator-free simulations per launch
-        if (!resume && (inner >= d.max_inner || levels_left <= 0)) {
+        if (!resume && (inner >= d.max_inner || levels_left <= 0 ||
+                        (d.time_budget > 0 && inner > 0 && (long long)(__builtin_amdgcn_s_memtime() - t_begin) > d.time_budget))) {
             st.capped += 1;
             break;
         }
@@ -1210,6 +1216,7 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     d.max_inner = cfg->max_inner_iters > 0 ? cfg->max_inner_iters
                                             : (cfg->eval_mode == C4_EVAL_CENTRE ? 1 << 20 : 1);
     d.level_budget = cfg->level_budget > 0 ? cfg->level_budget : 0;
+    d.time_budget = cfg->time_budget_cycles > 0 ? cfg->time_budget_cycles : 0;
     d.planes_dtype = cfg->planes_dtype;
     d.games_target = cfg->games_target;
     d.seed = cfg->seed;

@@ -25,8 +25,8 @@ class SelfPlay:
 
     def __init__(self, net: Callable, n_slots: int, config: MCTSConfig, seed: int = 0, device: int = 0,
                  games_target: int = -1, record_capacity_games: int = 0, planes_dtype=torch.float32,
-                 use_graph: bool = True, steps_per_graph: int = 8, max_inner_iters: int = 4,
-                 eval_cache_log2_entries: int = 0, level_budget: int = 0, pipeline: int = 1,
+                 use_graph: bool = True, steps_per_graph: int = 8, max_inner_iters: int = 32,
+                 eval_cache_log2_entries: int = 0, level_budget: int = 0, time_budget_cycles: int = 80000, pipeline: int = 1,
                  fused_loop: bool = False, steps_per_launch: int = 32):
         self.net = net
         self.n_slots = n_slots
@@ -35,7 +35,7 @@ class SelfPlay:
         self.engine = Engine(n_slots, eval_mode=L.EVAL_EXTERNAL_F32, rng_mode=L.RNG_PHILOX, seed=seed,
                              stop_after_move=False, games_target=games_target,
                              record_capacity_games=record_capacity_games, max_inner_iters=max_inner_iters,
-                             planes_dtype=_PLANES[planes_dtype], eval_cache_log2_entries=eval_cache_log2_entries, level_budget=level_budget,
+                             planes_dtype=_PLANES[planes_dtype], eval_cache_log2_entries=eval_cache_log2_entries, level_budget=level_budget, time_budget_cycles=time_budget_cycles,
                              device=device, **config.engine_kwargs())
         with torch.cuda.device(self.device):
             self.values = torch.zeros(n_slots, dtype=torch.float32, device=self.device)

@@ -90,7 +90,11 @@ typedef struct {
     int32_t level_budget;              /* descent levels a slot may walk per launch; a descent that runs
                                           out is suspended and resumed by the next launch, so no launch
                                           waits for the deepest tree of the batch.  0 = unlimited */
-    int32_t reserved[5];
+    int32_t time_budget_cycles;        /* a slot starts no further evaluator-free simulation once its step call
+                                          has run this many shader cycles (balances the waves of a launch by
+                                          cost instead of by count; which launch runs a simulation never
+                                          changes results).  0 = off */
+    int32_t reserved[4];
 } c4_config;
 
 typedef struct c4_engine c4_engine;

@@ -219,6 +219,10 @@ def test_eval_cache_is_transparent():
             return table(c0, c1)
         st = check_selfplay(case, L.EVAL_EXTERNAL_F32, fn, eval_cache_log2_entries=16, max_inner_iters=4,
                             level_budget=5)
+        # ... and with simulations rationed by elapsed cycles instead of by count
+        seen.clear()
+        check_selfplay(case, L.EVAL_EXTERNAL_F32, fn, eval_cache_log2_entries=16, max_inner_iters=32,
+                       time_budget_cycles=20000)
         assert st["eval_cache_hits"] > 0.2 * st["leaf_evals"]
         assert st["eval_cache_hits"] + len(seen) == st["leaf_evals"]
         assert len(seen) - len(set(seen)) <= 0.02 * len(seen)   # re-evaluations only after direct-mapped evictions

@@ -254,6 +254,7 @@ def main():
             "children_created_per_sec": children / elapsed,
             "moves_per_sec": moves / elapsed,
             "terminal_sim_fraction": term / max(1.0, sims),
+            "bad_evals": delta["bad_evals"],
             "eval_cache_hit_rate": (delta["eval_cache_hits"] / max(1, delta["eval_cache_probes"])),
             "mean_leaf_depth": mean_depth,
             "config": {

@@ -40,7 +40,7 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "simulations", "expansions", "children_created", "terminal_sims", "leaf_evals", "depth_sum",
         "moves", "games_started", "games_finished", "launches", "active_slots", "capped_slots",
-        "eval_cache_hits", "eval_cache_probes")]
+        "eval_cache_hits", "eval_cache_probes", "bad_evals")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -104,7 +104,7 @@ static_assert(sizeof(CacheEntry) == 48, "cache entry must be 48 bytes");
 
 struct SlotStats {  // per-slot counters (summed on the host; no atomics => deterministic)
     uint64_t sims, expansions, children, terminal_sims, leaf_evals, depth_sum, moves, games_started,
-        games_finished, capped, cache_hits, cache_probes;
+        games_finished, capped, cache_hits, cache_probes, bad_evals;
 };
 constexpr int N_STATS = sizeof(SlotStats) / sizeof(uint64_t);
 
@@ -419,7 +419,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
     int state = SLOT_ACTIVE;
     int has_leaf = 0;
     struct { uint32_t sims, expansions, children, terminal_sims, leaf_evals, depth_sum, moves, games_started,
-                      games_finished, capped, cache_hits, cache_probes; } st = {};
+                      games_finished, capped, cache_hits, cache_probes, bad_evals; } st = {};
     static_assert(sizeof(st) == N_STATS * 4, "launch-local stats mirror SlotStats");
 
     // evaluator answer for the pending leaf
@@ -470,6 +470,17 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
                 fresh_eval = false;
                 cache_insert(d, leaf0, leaf1, lane, (float)ev_value, (float)ev_prior);
             }
+            // The reference asserts that the net never answers NaN (model.py:258-263).  A NaN here would
+            // poison every comparison of the argmax, so answers are made finite first: memory safety of
+            // the walk must not depend on the evaluator (counted in stats as bad_evals).
+            {
+                const bool bad = !(ev_value >= 0.0 && ev_value <= 1.0) || !(ev_prior >= 0.0 && ev_prior <= 3.0e38);
+                if (__ballot(bad) >> (((threadIdx.x & 63) / GROUP) * GROUP) & 0xffull) {
+                    if (!(ev_value >= 0.0 && ev_value <= 1.0)) ev_value = 0.5;
+                    if (!(ev_prior >= 0.0 && ev_prior <= 3.0e38)) ev_prior = 0.0;
+                    st.bad_evals += 1;
+                }
+            }
             const uint64_t occ = leaf0 | leaf1;
             const int age = popc64(occ);
             const int mask = legal_mask(occ);                    // tree.py:23 valid_moves (leaf is undecided)
@@ -482,14 +493,14 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
                 float s = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 7; ++i) s = s + gshfl(pf, i);
-                prn = (double)(pf / s);
+                prn = s > 0.0f ? (double)(pf / s) : (legal ? 1.0 / (double)__popc(mask) : 0.0);
                 pf64 = 0;
             } else {
                 const double pd = legal ? ev_prior : 0.0;
                 double s = 0.0;
 #pragma unroll
                 for (int i = 0; i < 7; ++i) s = s + gshfl(pd, i);
-                prn = pd / s;
+                prn = s > 0.0 ? pd / s : (legal ? 1.0 / (double)__popc(mask) : 0.0);
                 pf64 = 1;
             }
             // mcts.py:171-181 add_exploration_noise (root only)
@@ -914,7 +925,9 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
     __shared__ __attribute__((aligned(16))) _Float16 act[2][(ROWS + 1) * CS];
     __shared__ __attribute__((aligned(16))) half8 wbuf[2][WCHUNKS];
     __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
-    __shared__ uint64_t sleaf[2][P];   // leaf bitboards handed from the tree phase to the net phase
+    __shared__ uint64_t sleaf[2][P];   // leaf bitboards handed from the tree phase to the net phase (compacted)
+    __shared__ int smap[P];            // compacted row -> slot of the workgroup
+    __shared__ int sn;                 // number of leaves this round
     static_assert((sizeof(PathEntry) * MAX_DEPTH + sizeof(Rec) * GROUP) * P <= sizeof(_Float16) * ROWS * CS, "tree-phase LDS must fit the activation buffer");
     // the tree phase's path stacks live in activation buffer 0, which the net overwrites afterwards
     PathEntry (*s_path)[MAX_DEPTH] = reinterpret_cast<PathEntry (*)[MAX_DEPTH]>(&act[0][0]);
@@ -934,13 +947,23 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
         const unsigned long long tc = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
         t_own += tb - ta;
         t_tree += tc - ta;
-        if (threadIdx.x < 2 * P) {
-            const int which = threadIdx.x / P, p = threadIdx.x - which * P;
-            sleaf[which][p] = which ? d.leaf_c1[slot0 + p] : d.leaf_c0[slot0 + p];
+        // compact the leaves: only slots that emitted one (cache miss) take a row of the network's batch;
+        // the network skips the tiles beyond the last real row
+        if (threadIdx.x < 64) {
+            const int p = threadIdx.x;
+            const bool has = p < P && slot0 + p < d.G && d.has_leaf[slot0 + p] != 0;
+            const unsigned long long m = __ballot(has);
+            if (has) {
+                const int j = __popcll(m & ((1ULL << p) - 1));
+                sleaf[0][j] = d.leaf_c0[slot0 + p];
+                sleaf[1][j] = d.leaf_c1[slot0 + p];
+                smap[j] = p;
+            }
+            if (p == 0) sn = __popcll(m);
         }
         __syncthreads();
-        net_forward_block(nd, NetLds{act, wbuf, mlp}, sleaf[0], sleaf[1], min(P, d.G - slot0), 0, values + slot0,
-                          priors + (size_t)slot0 * 7);
+        net_forward_block(nd, NetLds{act, wbuf, mlp}, sleaf[0], sleaf[1], sn, 0, values + slot0, priors + (size_t)slot0 * 7,
+                          smap);
         __syncthreads();   // values/priors written; LDS free for the next tree phase
         if (d.has_stamps) t_net += __builtin_amdgcn_s_memtime() - tc;
     }
@@ -1442,6 +1465,7 @@ int c4_get_stats(c4_engine *e, c4_stats *out)
     out->capped_slots = (int64_t)t.capped;
     out->eval_cache_hits = (int64_t)t.cache_hits;
     out->eval_cache_probes = (int64_t)t.cache_probes;
+    out->bad_evals = (int64_t)t.bad_evals;
     out->launches = e->launches;
     for (size_t g = 0; g < G; ++g) out->active_slots += stt[g] == SLOT_ACTIVE;
     return C4_OK;

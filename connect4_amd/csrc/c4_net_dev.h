@@ -112,8 +112,14 @@ constexpr size_t NET_LDS_BYTES = 2 * (ROWS + 1) * CS * sizeof(_Float16) + 2 * WC
 // One workgroup (NTHREADS threads) evaluates positions pos0 .. pos0+15.
 __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds &L, const uint64_t *__restrict__ c0,
                                                   const uint64_t *__restrict__ c1, int n, int pos0,
-                                                  float *__restrict__ values, float *__restrict__ priors)
+                                                  float *__restrict__ values, float *__restrict__ priors,
+                                                  const int *out_map = nullptr)
 {
+    // positions pos0 .. pos0+npos-1 are real; tiles that hold no real row are skipped in every stage
+    // (a wave-uniform test), which is what a compacted, partly filled leaf batch pays for.
+    // out_map (optional, P ints): output index of position p instead of pos0+p (compacted batches).
+    const int npos = min(max(n - pos0, 0), P);
+    const int ntiles = (npos * PIX + 31) / 32;
     _Float16 (*lds)[(ROWS + 1) * CS] = L.act;
     half8 (*wbuf)[WCHUNKS] = L.wbuf;
     float4 *mlp = L.mlp;
@@ -188,7 +194,7 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
         for (int s = 0; s < 3; ++s) w[s] = nd.stem_w[s * 64 + lane];
         float4 bias[4];
         load_bias(nd.stem_b, bias);
-        for (int t = wave; t < TILES; t += NWAVES) {
+        for (int t = wave; t < ntiles; t += NWAVES) {
             const int rg = t * 32 + r32;
             const int p = rg / PIX, pix = rg - p * PIX;
             const int y = pix / 7, x = pix - y * 7;
@@ -266,7 +272,7 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
         };
 #pragma unroll
         for (int ti = 0; ti < TPW; ++ti) {
-            if (wave + ti * NWAVES < TILES) {
+            if (wave + ti * NWAVES < ntiles) {
                 half8 bf[KSTEPS], xs[2];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) bf[s] = *reinterpret_cast<const half8 *>(src + rsel[ti][s >> 1] + (s & 1) * 16);
@@ -294,12 +300,13 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
                 pacc = acc;
                 prow = rbase[ti];
                 have_prev = true;
-                // the other weight buffer has been idle since the previous layer's barrier: park the
-                // prefetched weights there as soon as the first tile is done (frees 12 VGPRs)
-                if (ti == 0) commit(L + 1);
             }
+            // the other weight buffer has been idle since the previous layer's barrier: park the
+            // prefetched weights there as soon as the first tile is done (frees 12 VGPRs).  Every wave
+            // commits its share, also one that owns no tile of a partly filled batch.
+            if (ti == 0) commit(L + 1);
         }
-        store_tile(pacc, dst, prow, h);   // the wave's last tile has no chain to hide under
+        if (have_prev) store_tile(pacc, dst, prow, h);   // the wave's last tile has no chain to hide under
         if (L < 6) stamp(3 + L);
         __syncthreads();
     }
@@ -311,7 +318,7 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
     {
         const half8 w0 = nd.head_w[lane], w1 = nd.head_w[64 + lane];
         const float hb0 = nd.head_b[0], hb1 = nd.head_b[1], hb2 = nd.head_b[2];
-        for (int t = wave; t < TILES; t += NWAVES) {
+        for (int t = wave; t < ntiles; t += NWAVES) {
             const int rg = t * 32 + r32;
             const int p = rg / PIX, pix = rg - p * PIX;
             const half8 a0 = *reinterpret_cast<const half8 *>(lds[0] + rg * CS + 8 * h);
@@ -356,8 +363,11 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
 #pragma unroll
         for (int c = 0; c < 11; ++c) {
             const float wv = pt[c * 64 + lane];      // zero where seg*11 + c >= 84 or (lane & 7) == 7
-            l0 += wv * hpA[c];
-            l1 += wv * hpB[c];
+            // ... and there the read is clamped into this position's own planes: the entries behind
+            // them belong to the next position, which may be an empty row holding anything (0 * NaN)
+            const int cc = seg * 11 + c < 2 * PIX ? c : 2 * PIX - 1 - seg * 11;
+            l0 += wv * hpA[cc];
+            l1 += wv * hpB[cc];
         }
         // combine the 8 segments: lanes i and i^8 with a row rotate, the four 16-lane rows with two shuffles
         l0 += dppf<0x128>(l0);
@@ -373,7 +383,9 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
         for (int pp = 0; pp < 2; ++pp) {
             const float a = (pp ? a1 : a0) + fb;
             const float lg = (pp ? l1 : l0) + pb;
-            const int gp = pos0 + (pp ? pB : pA);
+            const int pq = pp ? pB : pA;
+            const int gp = pq < npos ? pos0 + pq : n;   // >= n: no output
+            const int go = out_map ? out_map[pq < npos ? pq : 0] : gp;
             const float rs = sum16(lane < PIX ? vw * lrelu(a) : 0.0f);               // model.py:83-85
             const float vsum = readlane_f(rs, 0) + readlane_f(rs, 16) + readlane_f(rs, 32);
             const float value = (tanhf(vsum + nd.vout_b) + nd.w1) * nd.w2;           // model.py:86-88
@@ -381,8 +393,8 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
             const float e = is_pol ? expf(lg - mx) : 0.0f;
             const float sum = sum8(e);
             if (gp < n) {
-                if (lane == 0) values[gp] = value;
-                if (is_pol) priors[(size_t)gp * 7 + lane] = e / sum;
+                if (lane == 0) values[go] = value;
+                if (is_pol) priors[(size_t)go * 7 + lane] = e / sum;
             }
         }
     }

@@ -115,6 +115,9 @@ typedef struct {
     int64_t capped_slots;       /* slot-launches that hit max_inner_iters */
     int64_t eval_cache_hits;    /* leaves answered by the evaluation cache (subset of leaf_evals) */
     int64_t eval_cache_probes;
+    int64_t bad_evals;          /* evaluator answers that were not finite / out of range and were replaced
+                                   (value 0.5, prior 0; an all-zero prior becomes uniform) -- the reference
+                                   asserts instead (model.py:258-263); must be 0 in a healthy run */
 } c4_stats;
 
 /* Root read-out of one slot (tree.py:66-117; what MCTS.make_move returns, mcts.py:88). */

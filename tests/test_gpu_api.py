@@ -193,3 +193,4 @@ def test_fused_selfplay_kernel_equals_separate_kernels():
     assert out[0][0] == out[1][0]
     for k in ("simulations", "expansions", "moves", "games_finished", "terminal_sims"):
         assert out[0][1][k] == out[1][1][k]
+    assert out[0][1]["bad_evals"] == 0 and out[1][1]["bad_evals"] == 0   # the net never answers NaN

@@ -235,3 +235,29 @@ def test_level_budget_suspension_is_transparent():
     for case in load_json("selfplay.json")[:2]:
         st = check_selfplay(case, L.EVAL_CENTRE, level_budget=3, max_inner_iters=2)
         assert st["capped_slots"] > 0
+
+
+def test_non_finite_evaluator_answers_are_contained():
+    """The reference asserts on NaN net outputs (model.py:258-263).  The engine must stay memory-safe:
+    NaN / out-of-range answers are replaced, counted in stats.bad_evals, and the search completes."""
+    from connect4_amd import _lib as L
+    c = dict(simulations=60, pb_c_base=19652, pb_c_init=1.25, root_dirichlet_alpha=0.0,
+             root_exploration_fraction=0.0, num_sampling_moves=0)
+    calls = [0]
+
+    def fn(c0, c1):
+        calls[0] += 1
+        p = np.full(7, 1.0 / 7.0, dtype=np.float32)
+        if calls[0] % 3 == 0:
+            p[:] = np.nan
+        if calls[0] % 5 == 0:
+            return np.float32(np.nan), p
+        return np.float32(0.5), p
+    with make_engine(c, 4, L.EVAL_EXTERNAL_F32, stop_after_move=True) as eng:
+        eng.reset()
+        drive_external(eng, fn, np.float32)
+        st = eng.stats()
+        roots = eng.read_roots()
+    assert st["bad_evals"] > 0 and st["simulations"] == 4 * 60
+    for r in roots:
+        assert r.state == 2 and 0 <= r.move < 7 and r.root_visits == 61

@@ -194,3 +194,25 @@ def test_fused_selfplay_kernel_equals_separate_kernels():
     for k in ("simulations", "expansions", "moves", "games_finished", "terminal_sims"):
         assert out[0][1][k] == out[1][1][k]
     assert out[0][1]["bad_evals"] == 0 and out[1][1]["bad_evals"] == 0   # the net never answers NaN
+
+
+def test_mini_generation_selfplay_train_reload(tmp_path):
+    """BASELINE configs[4] flow at toy size on one GPU: fused self-play -> data.pth -> train step ->
+    checkpoint -> the next generation's self-play runs on the updated weights."""
+    import os
+    import torch
+    from connect4_amd.config import MCTSConfig
+    from connect4_amd.generation import run_generation
+    from connect4_amd.training import ModelConfig, Trainer
+    torch.manual_seed(0)
+    tr = Trainer(ModelConfig(batch_size=256, n_training_epochs=2, use_gpu=True))
+    w0 = tr.net.state_dict()["body.0.0.weight"].detach().cpu().clone()
+    games0, loss0 = run_generation(tr, MCTSConfig.self_play(24), n_games=48, save_dir=str(tmp_path), gen=0, n_slots=48)
+    assert len(games0) == 48 and loss0 is not None and loss0 == loss0
+    d = torch.load(os.path.join(str(tmp_path), "0", "data.pth"), weights_only=True)
+    n_pos = sum(len(g.moves) for g in games0)
+    assert d["boards"].shape == (2 * n_pos, 3, 6, 7) and d["values"].shape == (2 * n_pos,) and d["priors"].shape == (2 * n_pos, 7)
+    assert os.path.exists(os.path.join(str(tmp_path), "0", "net.pth"))
+    assert not torch.equal(w0, tr.net.state_dict()["body.0.0.weight"].cpu())
+    games1, _ = run_generation(tr, MCTSConfig.self_play(24), n_games=48, save_dir=str(tmp_path), gen=1, n_slots=48)
+    assert len(games1) == 48

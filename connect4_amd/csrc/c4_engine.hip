@@ -131,6 +131,9 @@ struct Cold {
     int32_t *game_result;
     long long *game_tag;         // [rec_cap] id stored in the ring slot
     unsigned long long *next_game;
+    // speculative evaluation (fused self-play): a position queued for the network's spare rows
+    uint64_t *spec_c0, *spec_c1;
+    int32_t *spec_state;         // 0 none, 1 requested, 2 answered (answer in values[G+slot], priors[G+slot])
     unsigned long long *stamps;   // diagnostic (C4_TREE_STAMPS=1): [block][8] s_memtime values, first 256 blocks
 };
 
@@ -171,6 +174,7 @@ struct Dev {
     int rec_cap;
     int cache_bits;
     int has_stamps;          // diagnostic build aid enabled (C4_TREE_STAMPS=1)
+    int speculate;           // queue the most probable child of every network-evaluated leaf for the net's spare rows
     long long games_target;
     double alpha, frac;
     uint64_t seed;
@@ -376,6 +380,32 @@ __device__ __forceinline__ void cache_insert(const Dev &d, uint64_t c0, uint64_t
     if (lane == 0) { e->value = value; e->check = chk; e->key = key; }
 }
 
+// Speculative evaluation.  The first time an evaluated node is descended through, PUCT picks the child
+// with the largest prior (all values still 0, mcts.py:159-161, ties -> highest column) -- unless a
+// child wins outright.  So when the network answers for a leaf, its most probable non-terminal child
+// is the position the tree will ask about next; if it is not in the cache yet it is queued for one
+// of the rows the network's batch has to spare.  The answer only ever enters the evaluation cache,
+// so search results cannot change; the later probe simply hits.
+__device__ __forceinline__ void spec_request(const Dev &d, int g, int lane, uint64_t p0, uint64_t p1, double prior_lane,
+                                             bool legal_lane)
+{
+    uint64_t c0 = p0, c1 = p1;
+    uint32_t cst = ST_XWIN;
+    if (legal_lane) cst = make_move(c0, c1, lane);
+    const bool cand = legal_lane && cst == ST_FRESH;
+    const int kb = group_argmax(cand ? prior_lane : -1.0, cand ? lane : -1);
+    if (kb < 0) return;                         // every child is terminal
+    const uint64_t s0 = ((uint64_t)gshfl((uint32_t)(c0 >> 32), kb) << 32) | gshfl((uint32_t)c0, kb);
+    const uint64_t s1 = ((uint64_t)gshfl((uint32_t)(c1 >> 32), kb) << 32) | gshfl((uint32_t)c1, kb);
+    float cv, cp;
+    if (cache_probe(d, s0, s1, lane, cv, cp)) return;   // already known
+    if (lane == 0) {
+        d.cold->spec_c0[g] = s0;
+        d.cold->spec_c1[g] = s1;
+        d.cold->spec_state[g] = 1;
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void store_plane(void *planes, size_t idx, float v);
 template <> __device__ __forceinline__ void store_plane<float>(void *p, size_t i, float v) { ((float *)p)[i] = v; }
@@ -448,6 +478,21 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
     stamp(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(1);
+    // speculative answer from the previous network pass: into the cache, then look one ply further
+    if (EVAL == C4_EVAL_EXTERNAL_F32 && d.speculate && d.cache && d.cold->spec_state[g] == 2) {
+        const uint64_t q0 = d.cold->spec_c0[g], q1 = d.cold->spec_c1[g];
+        const float sv = ((const float *)values_in)[d.G + g];
+        const float sp = lane < 7 ? ((const float *)priors_in)[(size_t)(d.G + g) * 7 + lane] : 0.0f;
+        if (lane == 0) d.cold->spec_state[g] = 0;
+        const bool okv = sv >= 0.0f && sv <= 1.0f && sp >= 0.0f && sp <= 3.0e38f;
+        if (!((__ballot(!okv) >> (((threadIdx.x & 63) / GROUP) * GROUP)) & 0xffull)) {
+            cache_insert(d, q0, q1, lane, sv, sp);
+            const int qm = legal_mask(q0 | q1);
+            const bool ql = lane < 7 && ((qm >> lane) & 1);
+            spec_request(d, g, lane, q0, q1, ql ? (double)sp : -1.0, ql);
+        }
+    }
+
     // A slot may walk at most `level_budget` descent levels per launch; a descent that runs out is
     // suspended (node, board and path are saved) and resumed by the next launch.  Every wave then
     // does about the same amount of work per launch instead of waiting for the deepest tree.
@@ -466,9 +511,11 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
         // ---------------------------------------------------------------- evaluate_node + expand + backup
         if (apply_now) {
             apply_now = false;
+            bool want_spec = false;
             if (fresh_eval) {   // evaluators.py:21-24: position_table[key] = evaluate_fn(board)
                 fresh_eval = false;
                 cache_insert(d, leaf0, leaf1, lane, (float)ev_value, (float)ev_prior);
+                want_spec = d.speculate != 0;
             }
             // The reference asserts that the net never answers NaN (model.py:258-263).  A NaN here would
             // poison every comparison of the argmax, so answers are made finite first: memory safety of
@@ -521,6 +568,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
                 prn = a + b;
                 pf64 = 1;
             }
+            if (want_spec) spec_request(d, g, lane, leaf0, leaf1, prn, legal);   // prn: the prior PUCT will see
             // tree.py:119-132: children in ascending column order, one 8-aligned block
             const uint32_t nchild = (uint32_t)__popc(mask);
             const uint32_t base = nalloc * GROUP;
@@ -959,7 +1007,22 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
                 sleaf[1][j] = d.leaf_c1[slot0 + p];
                 smap[j] = p;
             }
-            if (p == 0) sn = __popcll(m);
+            const int k = __popcll(m);
+            // spare rows: speculative requests (answers go to values[G+slot] / priors[G+slot])
+            const bool sp = d.speculate && p < P && slot0 + p < d.G && d.cold->spec_state[slot0 + p] == 1;
+            const unsigned long long ms = __ballot(sp);
+            int ns = 0;
+            if (sp) {
+                const int j = k + __popcll(ms & ((1ULL << p) - 1));
+                if (j < P) {
+                    sleaf[0][j] = d.cold->spec_c0[slot0 + p];
+                    sleaf[1][j] = d.cold->spec_c1[slot0 + p];
+                    smap[j] = d.G + p;
+                    d.cold->spec_state[slot0 + p] = 2;
+                }
+            }
+            ns = min(P - k, (int)__popcll(ms));
+            if (p == 0) sn = k + ns;
         }
         __syncthreads();
         net_forward_block(nd, NetLds{act, wbuf, mlp}, sleaf[0], sleaf[1], sn, 0, values + slot0, priors + (size_t)slot0 * 7,
@@ -987,6 +1050,7 @@ __global__ void c4_reset_kernel(Dev d, const uint64_t *c0, const uint64_t *c1, i
     d.leaf_c0[g] = 0;
     d.leaf_c1[g] = 0;
     d.has_leaf[g] = 0;
+    d.cold->spec_state[g] = 0;
     d.pending[g] = -1;
     d.pending_depth[g] = 0;
     d.pending_info[g] = 0;
@@ -1240,6 +1304,7 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
                                             : (cfg->eval_mode == C4_EVAL_CENTRE ? 1 << 20 : 1);
     d.level_budget = cfg->level_budget > 0 ? cfg->level_budget : 0;
     d.time_budget = cfg->time_budget_cycles > 0 ? cfg->time_budget_cycles : 0;
+    d.speculate = cfg->speculate ? 1 : 0;
     d.planes_dtype = cfg->planes_dtype;
     d.games_target = cfg->games_target;
     d.seed = cfg->seed;
@@ -1261,6 +1326,7 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     ALLOC(d.stats, G * N_STATS);
     ALLOC(e->cold.res_move, G); ALLOC(e->cold.res_value, G); ALLOC(e->cold.res_policy, G * 7);
     ALLOC(e->cold.next_game, 1);
+    ALLOC(e->cold.spec_c0, G); ALLOC(e->cold.spec_c1, G); ALLOC(e->cold.spec_state, G);
     const size_t R = (size_t)d.rec_cap;
     ALLOC(e->cold.rec_c0, R * 42); ALLOC(e->cold.rec_c1, R * 42); ALLOC(e->cold.rec_move, R * 42);
     ALLOC(e->cold.rec_value, R * 42); ALLOC(e->cold.rec_policy, R * 42 * 7);

@@ -94,7 +94,12 @@ typedef struct {
                                           has run this many shader cycles (balances the waves of a launch by
                                           cost instead of by count; which launch runs a simulation never
                                           changes results).  0 = off */
-    int32_t reserved[4];
+    int32_t speculate;                 /* fused self-play only: queue the most probable child of every
+                                          network-evaluated leaf for the spare rows of the network's batch;
+                                          answers only enter the evaluation cache (results unchanged).
+                                          values_dev / priors_dev of c4_selfplay_steps must then hold
+                                          2*n_slots rows (second half = speculative answers) */
+    int32_t reserved[3];
 } c4_config;
 
 typedef struct c4_engine c4_engine;
@@ -252,7 +257,8 @@ const char *c4_net_last_error(void);
 /* Fused persistent self-play: n_steps rounds of {c4_step for 16 slots; c4_net_forward on their 16
  * leaves} per workgroup in ONE launch -- no kernel boundary, no global barrier, a workgroup waits only
  * for its own 16 trees.  Same results as alternating c4_step / c4_net_forward.  values_dev float32
- * [n_slots], priors_dev float32 [n_slots][7] are the hand-off buffers (must persist between calls).
+ * [n_slots], priors_dev float32 [n_slots][7] are the hand-off buffers (must persist between calls; twice
+ * as many rows when c4_config.speculate is set).
  * Needs C4_EVAL_EXTERNAL_F32 and n_slots % 16 == 0. */
 int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *priors_dev, int32_t n_steps,
                       void *hip_stream);

@@ -178,9 +178,9 @@ def test_fused_selfplay_kernel_equals_separate_kernels():
     net = FusedNet(random_init_state_dict(seed=0))
     cfg = MCTSConfig.self_play(48)
     out = []
-    for fused in (False, True):
+    for fused in (False, True):   # the fused run also speculates (answers only enter the cache)
         sp = SelfPlay(net, 64, cfg, seed=11, games_target=96, record_capacity_games=96, use_graph=False,
-                      fused_loop=fused, steps_per_launch=16, max_inner_iters=3)
+                      fused_loop=fused, steps_per_launch=16, max_inner_iters=3, speculate=True)
         for _ in range(400):
             sp.run_steps(64)
             if sp.stats()["active_slots"] == 0:

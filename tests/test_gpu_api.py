@@ -257,3 +257,17 @@ def test_end_to_end_net_driven_search_matches_reference():
                 assert tv < 0.08, (case["name"], got, ref_n, tv)
                 assert tree.best_move().name == case["best_move"], case["name"]
     assert exact == len(cases)
+
+
+def test_wide_net_falls_back_to_pytorch_plan():
+    """example_config's 64-filter / 6-block / 6-fc net (data/example_config.py:8-16): no fused kernel for
+    that width, the factory returns the PyTorch-ROCm plan and self-play works unchanged."""
+    from connect4_amd.config import MCTSConfig
+    from connect4_amd.fused_net import FusedNet, make_selfplay_net
+    from connect4_amd.net import InferenceNet, NetConfig, random_init_state_dict
+    from connect4_amd.selfplay import generate_games
+    wide = make_selfplay_net(random_init_state_dict(NetConfig(filters=64, n_fc_layers=6, n_residuals=6), seed=0))
+    assert isinstance(wide, InferenceNet)
+    assert isinstance(make_selfplay_net(random_init_state_dict(seed=0)), FusedNet)
+    games = generate_games(MCTSConfig.self_play(16), wide, n_games=8, n_slots=8, seed=0)
+    assert len(games) == 8 and all(g.result is not None for g in games)

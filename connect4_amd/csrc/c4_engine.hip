@@ -108,6 +108,21 @@ struct SlotStats {  // per-slot counters (summed on the host; no atomics => dete
 };
 constexpr int N_STATS = sizeof(SlotStats) / sizeof(uint64_t);
 
+// One slot's state as the fused self-play kernel keeps it in LDS between its steps (loaded from the
+// Dev arrays when the launch starts, written back when it ends): a step then begins and ends without
+// a global-memory round trip, and the leaf hand-over to the network phase never leaves the CU.
+struct SlotMem {
+    uint64_t root0, root1, leaf0, leaf1;
+    long long gid;
+    uint32_t sims, nalloc;
+    int32_t pend;
+    uint32_t pdepth, pinfo;
+    int32_t need_root;
+    uint32_t ply;
+    int32_t state, has_leaf;
+    uint32_t stats[N_STATS];   // counters of this launch, added to Dev::stats once at its end
+};
+
 // Rarely touched pointers (move choice, game end, suspended descents, diagnostics) live in device
 // memory behind one pointer: a kernel argument block with ~60 pointers does not fit the scalar
 // register file and the spills land in the descent loop.
@@ -418,34 +433,49 @@ template <> __device__ __forceinline__ void store_plane<hip_bfloat16>(void *p, s
 // One rollout step of slot `g` by its 8-lane group (`gl` = the group's row in s_path).  Called by the
 // standalone step kernel and by the fused self-play kernel.  `leaf_out` (optional, LDS or global) gets
 // the emitted leaf's bitboards {color0, color1} or {0,0} when the slot emits nothing.
-template <int EVAL, bool STAMPS = true>
+// `sm` (fused kernel): the slot's state lives in LDS for the whole launch; the evaluator's answers are
+// then read at values_in[ai] / priors_in[ai*7..] (LDS as well).  Without `sm` the state is read from
+// and written to the Dev arrays and ai == g.
+template <int EVAL, bool STAMPS = true, bool LDS_STATE = false>
 __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int lane, const int gl,
                                           PathEntry (*s_path)[MAX_DEPTH], Rec (*s_l1)[GROUP],
                                           const void *__restrict__ values_in,
                                           const void *__restrict__ priors_in, void *__restrict__ planes_out,
-                                          uint64_t *leaf_out)
+                                          uint64_t *leaf_out, SlotMem *sm = nullptr, const int ai_lds = 0,
+                                          const int si_lds = 0)
 {
     if (leaf_out && lane < 2) leaf_out[lane] = 0;
     if (g >= d.slot_hi) return;
-    if (d.state[g] != SLOT_ACTIVE) {
+    if (LDS_STATE) {
+        if (sm->state != SLOT_ACTIVE) {
+            if (lane == 0) sm->has_leaf = 0;
+            return;
+        }
+    } else if (d.state[g] != SLOT_ACTIVE) {
         if (lane == 0) d.has_leaf[g] = 0;
         return;
     }
     constexpr bool SCORE_F32 = (EVAL == C4_EVAL_EXTERNAL_F32);
+    const int ai = LDS_STATE ? ai_lds : g;            // row of the evaluator's answer for this slot
+    const int si = LDS_STATE ? si_lds : d.G + g;      // row of the answer to its speculative request
 
     const Pool pool{d.pool + (size_t)g * d.cap * (BLOCK_BYTES / 8)};
     PathEntry *gpath = d.path + (size_t)g * MAX_DEPTH;
 
     // slot state (group-uniform registers)
-    uint64_t root0 = d.root_c0[g], root1 = d.root_c1[g];
-    uint32_t sims = d.sims_done[g];
-    uint32_t nalloc = d.n_alloc[g];
-    int32_t pend = d.pending[g];
-    uint32_t pdepth = d.pending_depth[g];
-    uint32_t pinfo = d.pending_info[g];
-    int32_t need_root = d.need_root[g];
-    uint32_t ply = d.ply[g];
-    long long gid = d.game_id[g];
+    uint64_t root0, root1;
+    uint32_t sims, nalloc, pdepth, pinfo, ply;
+    int32_t pend, need_root;
+    long long gid;
+    if (LDS_STATE) {
+        root0 = sm->root0; root1 = sm->root1;
+        sims = sm->sims; nalloc = sm->nalloc; pend = sm->pend; pdepth = sm->pdepth; pinfo = sm->pinfo;
+        need_root = sm->need_root; ply = sm->ply; gid = sm->gid;
+    } else {
+        root0 = d.root_c0[g]; root1 = d.root_c1[g];
+        sims = d.sims_done[g]; nalloc = d.n_alloc[g]; pend = d.pending[g]; pdepth = d.pending_depth[g];
+        pinfo = d.pending_info[g]; need_root = d.need_root[g]; ply = d.ply[g]; gid = d.game_id[g];
+    }
     int state = SLOT_ACTIVE;
     int has_leaf = 0;
     struct { uint32_t sims, expansions, children, terminal_sims, leaf_evals, depth_sum, moves, games_started,
@@ -459,14 +489,14 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
     bool path_lds = (EVAL == C4_EVAL_CENTRE);   // where the pending leaf's descent path lives
     bool fresh_eval = false;                    // the answer came from the evaluator: remember it
     if (pend >= 0) {
-        leaf0 = d.leaf_c0[g];
-        leaf1 = d.leaf_c1[g];
+        leaf0 = LDS_STATE ? sm->leaf0 : d.leaf_c0[g];
+        leaf1 = LDS_STATE ? sm->leaf1 : d.leaf_c1[g];
         if (EVAL == C4_EVAL_EXTERNAL_F32) {
-            ev_value = (double)((const float *)values_in)[g];
-            ev_prior = lane < 7 ? (double)((const float *)priors_in)[(size_t)g * 7 + lane] : 0.0;
+            ev_value = (double)((const float *)values_in)[ai];
+            ev_prior = lane < 7 ? (double)((const float *)priors_in)[(size_t)ai * 7 + lane] : 0.0;
         } else if (EVAL == C4_EVAL_EXTERNAL_F64) {
-            ev_value = ((const double *)values_in)[g];
-            ev_prior = lane < 7 ? ((const double *)priors_in)[(size_t)g * 7 + lane] : 0.0;
+            ev_value = ((const double *)values_in)[ai];
+            ev_prior = lane < 7 ? ((const double *)priors_in)[(size_t)ai * 7 + lane] : 0.0;
         }
         apply_now = true;   // (C4_EVAL_CENTRE never leaves a leaf pending across launches)
         fresh_eval = (EVAL == C4_EVAL_EXTERNAL_F32) && d.cache != nullptr;
@@ -481,8 +511,8 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
     // speculative answer from the previous network pass: into the cache, then look one ply further
     if (EVAL == C4_EVAL_EXTERNAL_F32 && d.speculate && d.cache && d.cold->spec_state[g] == 2) {
         const uint64_t q0 = d.cold->spec_c0[g], q1 = d.cold->spec_c1[g];
-        const float sv = ((const float *)values_in)[d.G + g];
-        const float sp = lane < 7 ? ((const float *)priors_in)[(size_t)(d.G + g) * 7 + lane] : 0.0f;
+        const float sv = ((const float *)values_in)[si];
+        const float sp = lane < 7 ? ((const float *)priors_in)[(size_t)si * 7 + lane] : 0.0f;
         if (lane == 0) d.cold->spec_state[g] = 0;
         const bool okv = sv >= 0.0f && sv <= 1.0f && sp >= 0.0f && sp <= 3.0e38f;
         if (!((__ballot(!okv) >> (((threadIdx.x & 63) / GROUP) * GROUP)) & 0xffull)) {
@@ -771,8 +801,8 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
             cinfo = pinfo;
             cN = d.cold->cont_n[g];
             cW = d.cold->cont_w[g];
-            b0 = d.leaf_c0[g];
-            b1 = d.leaf_c1[g];
+            b0 = LDS_STATE ? sm->leaf0 : d.leaf_c0[g];
+            b1 = LDS_STATE ? sm->leaf1 : d.leaf_c1[g];
             depth = pdepth;
             for (uint32_t i = lane; i <= depth; i += GROUP) s_path[gl][i] = gpath[i];
             pend = -1;
@@ -847,8 +877,8 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
                 d.cold->cont_cur[g] = cur;
                 d.cold->cont_n[g] = cN;
                 d.cold->cont_w[g] = cW;
-                d.leaf_c0[g] = b0;
-                d.leaf_c1[g] = b1;
+                if (LDS_STATE) { sm->leaf0 = b0; sm->leaf1 = b1; }
+                else { d.leaf_c0[g] = b0; d.leaf_c1[g] = b1; }
             }
             pend = -2;
             pdepth = depth;
@@ -911,7 +941,10 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
     // ---------------------------------------------------------------- emit leaf + persist slot state
     stamp(4);
     if (has_leaf) {
-        if (lane == 0) { d.leaf_c0[g] = leaf0; d.leaf_c1[g] = leaf1; }
+        if (lane == 0) {
+            if (LDS_STATE) { sm->leaf0 = leaf0; sm->leaf1 = leaf1; }
+            else { d.leaf_c0[g] = leaf0; d.leaf_c1[g] = leaf1; }
+        }
         if (leaf_out && lane == 0) { leaf_out[0] = leaf0; leaf_out[1] = leaf1; }
         if (planes_out) {
             const int o_to_move = (popc64(leaf0 | leaf1) & 1) ? 0 : 1;
@@ -923,6 +956,28 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
                 else store_plane<hip_bfloat16>(planes_out, pb + e, v);
             }
         }
+    }
+    if (LDS_STATE) {
+        // node records, cache lines and game records drain in the background: only this group reads
+        // them back, and a wave's own memory operations stay in order
+        if (lane == 0) {
+            sm->has_leaf = has_leaf;
+            sm->root0 = root0;
+            sm->root1 = root1;
+            sm->sims = sims;
+            sm->nalloc = nalloc;
+            sm->pend = (has_leaf || pend == -2) ? pend : -1;
+            sm->pdepth = pdepth;
+            sm->pinfo = pinfo;
+            sm->need_root = need_root;
+            sm->ply = ply;
+            sm->gid = gid;
+            sm->state = state;
+            const uint32_t *sv = (const uint32_t *)&st;
+#pragma unroll
+            for (int i = 0; i < N_STATS; ++i) sm->stats[i] += sv[i];
+        }
+        return;
     }
     if (lane == 0) {
         d.has_leaf[g] = has_leaf;
@@ -974,8 +1029,11 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
     __shared__ __attribute__((aligned(16))) half8 wbuf[2][WCHUNKS];
     __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
     __shared__ uint64_t sleaf[2][P];   // leaf bitboards handed from the tree phase to the net phase (compacted)
-    __shared__ int smap[P];            // compacted row -> slot of the workgroup
+    __shared__ int smap[P];            // compacted row -> answer row
     __shared__ int sn;                 // number of leaves this round
+    __shared__ SlotMem smem[P];        // the workgroup's slot states, LDS-resident for the whole launch
+    __shared__ float s_val[2 * P];     // network answers: rows 0..P-1 the slots' leaves, P.. their speculative requests
+    __shared__ float s_pri[2 * P * 7];
     static_assert((sizeof(PathEntry) * MAX_DEPTH + sizeof(Rec) * GROUP) * P <= sizeof(_Float16) * ROWS * CS, "tree-phase LDS must fit the activation buffer");
     // the tree phase's path stacks live in activation buffer 0, which the net overwrites afterwards
     PathEntry (*s_path)[MAX_DEPTH] = reinterpret_cast<PathEntry (*)[MAX_DEPTH]>(&act[0][0]);
@@ -986,12 +1044,35 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
     // lock-step and wait for each other's deeper trees, so spreading them over waves shortens the phase
     const int wv = threadIdx.x >> 6, grp = (threadIdx.x & 63) / GROUP;
     const int sl = wv + NWAVES * grp;     // slot of this 8-lane group inside the workgroup (grp < 2)
+    // ---- launch prologue: slot states and the pending network answers, global -> LDS
+    if (threadIdx.x < P) {
+        const int p = threadIdx.x, g = slot0 + p;
+        SlotMem m = {};
+        m.state = SLOT_PARKED;
+        if (g < d.G) {
+            m.root0 = d.root_c0[g]; m.root1 = d.root_c1[g]; m.leaf0 = d.leaf_c0[g]; m.leaf1 = d.leaf_c1[g];
+            m.gid = d.game_id[g]; m.sims = d.sims_done[g]; m.nalloc = d.n_alloc[g]; m.pend = d.pending[g];
+            m.pdepth = d.pending_depth[g]; m.pinfo = d.pending_info[g]; m.need_root = d.need_root[g];
+            m.ply = d.ply[g]; m.state = d.state[g]; m.has_leaf = d.has_leaf[g];
+        }
+        smem[p] = m;
+    }
+    for (int i = threadIdx.x; i < 2 * P * 8; i += NTHREADS) {   // answers of the previous launch (+ speculative rows)
+        const int row = i >> 3, k = i & 7, p = row % P;
+        const int src = (row < P ? 0 : d.G) + slot0 + p;
+        const bool ok = slot0 + p < d.G && (row < P || d.speculate);
+        if (k == 7) s_val[row] = ok ? values[src] : 0.0f;
+        else s_pri[row * 7 + k] = ok ? priors[(size_t)src * 7 + k] : 0.0f;
+    }
+    __syncthreads();
     unsigned long long t_tree = 0, t_net = 0, t_own = 0;   // diagnostic (C4_TREE_STAMPS=1)
     for (int step = 0; step < n_steps; ++step) {
         const unsigned long long ta = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
-        if (grp < P / NWAVES) tree_step<C4_EVAL_EXTERNAL_F32, false>(d, slot0 + sl, lane, sl, s_path, s_l1, values, priors, nullptr, nullptr);
+        if (grp < P / NWAVES)
+            tree_step<C4_EVAL_EXTERNAL_F32, false, true>(d, slot0 + sl, lane, sl, s_path, s_l1, s_val, s_pri, nullptr, nullptr,
+                                                         &smem[sl], sl, P + sl);
         const unsigned long long tb = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
-        __syncthreads();   // tree-phase global stores (leaf boards, node records) are visible to the whole CU
+        __syncthreads();   // slot states (LDS) are visible to the whole workgroup
         const unsigned long long tc = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
         t_own += tb - ta;
         t_tree += tc - ta;
@@ -999,16 +1080,16 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
         // the network skips the tiles beyond the last real row
         if (threadIdx.x < 64) {
             const int p = threadIdx.x;
-            const bool has = p < P && slot0 + p < d.G && d.has_leaf[slot0 + p] != 0;
+            const bool has = p < P && smem[p < P ? p : 0].has_leaf != 0;
             const unsigned long long m = __ballot(has);
             if (has) {
                 const int j = __popcll(m & ((1ULL << p) - 1));
-                sleaf[0][j] = d.leaf_c0[slot0 + p];
-                sleaf[1][j] = d.leaf_c1[slot0 + p];
+                sleaf[0][j] = smem[p].leaf0;
+                sleaf[1][j] = smem[p].leaf1;
                 smap[j] = p;
             }
             const int k = __popcll(m);
-            // spare rows: speculative requests (answers go to values[G+slot] / priors[G+slot])
+            // spare rows: speculative requests (answers go to rows P + slot)
             const bool sp = d.speculate && p < P && slot0 + p < d.G && d.cold->spec_state[slot0 + p] == 1;
             const unsigned long long ms = __ballot(sp);
             int ns = 0;
@@ -1017,7 +1098,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
                 if (j < P) {
                     sleaf[0][j] = d.cold->spec_c0[slot0 + p];
                     sleaf[1][j] = d.cold->spec_c1[slot0 + p];
-                    smap[j] = d.G + p;
+                    smap[j] = P + p;
                     d.cold->spec_state[slot0 + p] = 2;
                 }
             }
@@ -1025,15 +1106,33 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
             if (p == 0) sn = k + ns;
         }
         __syncthreads();
-        net_forward_block(nd, NetLds{act, wbuf, mlp}, sleaf[0], sleaf[1], sn, 0, values + slot0, priors + (size_t)slot0 * 7,
-                          smap);
-        __syncthreads();   // values/priors written; LDS free for the next tree phase
+        net_forward_block(nd, NetLds{act, wbuf, mlp}, sleaf[0], sleaf[1], sn, 0, s_val, s_pri, smap);
+        __syncthreads();   // answers written; LDS free for the next tree phase
         if (d.has_stamps) t_net += __builtin_amdgcn_s_memtime() - tc;
     }
-    if (d.has_stamps && blockIdx.x < 256 && (threadIdx.x & 63) == 0) {
-        unsigned long long *o = d.cold->stamps + blockIdx.x * 8;
-        if (wv == 0) { o[0] = t_tree; o[1] = t_net; o[2] = (unsigned long long)n_steps; }
-        if (wv < 5) o[3 + wv] = t_own;   // this wave's own tree work (waves 0..4)
+    // ---- launch epilogue: LDS -> global (the next launch, c4_step, read-outs and the host see the Dev arrays)
+    if (threadIdx.x < P && slot0 + threadIdx.x < d.G) {
+        const int p = threadIdx.x, g = slot0 + p;
+        const SlotMem m = smem[p];
+        d.root_c0[g] = m.root0; d.root_c1[g] = m.root1; d.leaf_c0[g] = m.leaf0; d.leaf_c1[g] = m.leaf1;
+        d.game_id[g] = m.gid; d.sims_done[g] = m.sims; d.n_alloc[g] = m.nalloc; d.pending[g] = m.pend;
+        d.pending_depth[g] = m.pdepth; d.pending_info[g] = m.pinfo; d.need_root[g] = m.need_root;
+        d.ply[g] = m.ply; d.state[g] = m.state; d.has_leaf[g] = m.has_leaf;
+        uint64_t *sp = d.stats + (size_t)g * N_STATS;
+        for (int i = 0; i < N_STATS; ++i) sp[i] += m.stats[i];
+    }
+    for (int i = threadIdx.x; i < 2 * P * 8; i += NTHREADS) {
+        const int row = i >> 3, k = i & 7, p = row % P;
+        const int dst = (row < P ? 0 : d.G) + slot0 + p;
+        if (slot0 + p < d.G && (row < P || d.speculate)) {
+            if (k == 7) values[dst] = s_val[row];
+            else priors[(size_t)dst * 7 + k] = s_pri[row * 7 + k];
+        }
+    }
+    if (d.has_stamps && blockIdx.x < 128 && (threadIdx.x & 63) == 0) {   // rows 2b: per-wave own tree work, 2b+1: phases
+        unsigned long long *o = d.cold->stamps + blockIdx.x * 16;
+        o[wv] = t_own;
+        if (wv == 0) { o[8] = t_tree; o[9] = t_net; o[10] = (unsigned long long)n_steps; }
     }
 }
 

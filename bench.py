@@ -92,7 +92,6 @@ def main():
                     help="2: two half-batches on two streams, tree kernel of one half under the net of the other")
     ap.add_argument("--fused-loop", type=int, default=1, help="1: tree step + net in one persistent kernel")
     ap.add_argument("--steps-per-launch", type=int, default=32)
-    ap.add_argument("--speculate", type=int, default=0, help="fused loop: evaluate the most probable child of each new leaf in spare net rows")
     ap.add_argument("--pmc-mode", action="store_true",
                     help="for rocprofv3 --pmc passes: warm up with the fused kernel, then run the timed steps as "
                          "separate eager launches (no HIP graph: PMC collection crashes inside graph replay)")
@@ -145,8 +144,7 @@ def main():
                   games_target=-1, record_capacity_games=2 * args.slots, planes_dtype=tdt,
                   use_graph=not args.no_graph, steps_per_graph=args.steps_per_graph, max_inner_iters=args.max_inner,
                   eval_cache_log2_entries=args.eval_cache, level_budget=args.level_budget, time_budget_cycles=args.time_budget, pipeline=args.pipeline,
-                  fused_loop=bool(args.fused_loop), steps_per_launch=args.steps_per_launch,
-                  speculate=bool(args.speculate))
+                  fused_loop=bool(args.fused_loop), steps_per_launch=args.steps_per_launch)
 
     def barrier():
         if world > 1:
@@ -265,7 +263,7 @@ def main():
                 "slots_per_gpu": args.slots, "simulations": args.sims, "net": "32f-3res-4fc",
                 "net_impl": args.net, "net_dtype": args.net_dtype, "tree_dtype": "u64 bitboards, u32 visits, f64 value sums/priors",
                 "parallelism": "games sharded over %d GPU(s), no collective in the rollout path" % world,
-                "max_inner_iters": args.max_inner, "eval_cache_log2_entries": args.eval_cache, "level_budget": args.level_budget, "time_budget_cycles": args.time_budget, "pipeline_halves": args.pipeline, "fused_loop": bool(args.fused_loop), "steps_per_launch": args.steps_per_launch, "speculate": bool(args.speculate and args.fused_loop), "hip_graph": (not args.no_graph), "steps_per_graph": args.steps_per_graph,
+                "max_inner_iters": args.max_inner, "eval_cache_log2_entries": args.eval_cache, "level_budget": args.level_budget, "time_budget_cycles": args.time_budget, "pipeline_halves": args.pipeline, "fused_loop": bool(args.fused_loop), "steps_per_launch": args.steps_per_launch, "hip_graph": (not args.no_graph), "steps_per_graph": args.steps_per_graph,
                 "dirichlet_alpha": 0.3, "exploration_fraction": 0.25, "num_sampling_moves": 6,
             },
         }

@@ -33,7 +33,7 @@ class Config(C.Structure):
                 ("num_sampling_moves", C.c_int32), ("eval_mode", C.c_int32), ("rng_mode", C.c_int32),
                 ("seed", C.c_uint64), ("stop_after_move", C.c_int32), ("games_target", C.c_int64),
                 ("record_capacity_games", C.c_int32), ("max_inner_iters", C.c_int32),
-                ("planes_dtype", C.c_int32), ("eval_cache_log2_entries", C.c_int32), ("level_budget", C.c_int32), ("time_budget_cycles", C.c_int32), ("speculate", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("planes_dtype", C.c_int32), ("eval_cache_log2_entries", C.c_int32), ("level_budget", C.c_int32), ("time_budget_cycles", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class Stats(C.Structure):

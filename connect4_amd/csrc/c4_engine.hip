@@ -120,7 +120,6 @@ struct SlotMem {
     int32_t need_root;
     uint32_t ply;
     int32_t state, has_leaf;
-    uint32_t stats[N_STATS];   // counters of this launch, added to Dev::stats once at its end
 };
 
 // Rarely touched pointers (move choice, game end, suspended descents, diagnostics) live in device
@@ -146,9 +145,6 @@ struct Cold {
     int32_t *game_result;
     long long *game_tag;         // [rec_cap] id stored in the ring slot
     unsigned long long *next_game;
-    // speculative evaluation (fused self-play): a position queued for the network's spare rows
-    uint64_t *spec_c0, *spec_c1;
-    int32_t *spec_state;         // 0 none, 1 requested, 2 answered (answer in values[G+slot], priors[G+slot])
     unsigned long long *stamps;   // diagnostic (C4_TREE_STAMPS=1): [block][8] s_memtime values, first 256 blocks
 };
 
@@ -189,7 +185,6 @@ struct Dev {
     int rec_cap;
     int cache_bits;
     int has_stamps;          // diagnostic build aid enabled (C4_TREE_STAMPS=1)
-    int speculate;           // queue the most probable child of every network-evaluated leaf for the net's spare rows
     long long games_target;
     double alpha, frac;
     uint64_t seed;
@@ -395,32 +390,6 @@ __device__ __forceinline__ void cache_insert(const Dev &d, uint64_t c0, uint64_t
     if (lane == 0) { e->value = value; e->check = chk; e->key = key; }
 }
 
-// Speculative evaluation.  The first time an evaluated node is descended through, PUCT picks the child
-// with the largest prior (all values still 0, mcts.py:159-161, ties -> highest column) -- unless a
-// child wins outright.  So when the network answers for a leaf, its most probable non-terminal child
-// is the position the tree will ask about next; if it is not in the cache yet it is queued for one
-// of the rows the network's batch has to spare.  The answer only ever enters the evaluation cache,
-// so search results cannot change; the later probe simply hits.
-__device__ __forceinline__ void spec_request(const Dev &d, int g, int lane, uint64_t p0, uint64_t p1, double prior_lane,
-                                             bool legal_lane)
-{
-    uint64_t c0 = p0, c1 = p1;
-    uint32_t cst = ST_XWIN;
-    if (legal_lane) cst = make_move(c0, c1, lane);
-    const bool cand = legal_lane && cst == ST_FRESH;
-    const int kb = group_argmax(cand ? prior_lane : -1.0, cand ? lane : -1);
-    if (kb < 0) return;                         // every child is terminal
-    const uint64_t s0 = ((uint64_t)gshfl((uint32_t)(c0 >> 32), kb) << 32) | gshfl((uint32_t)c0, kb);
-    const uint64_t s1 = ((uint64_t)gshfl((uint32_t)(c1 >> 32), kb) << 32) | gshfl((uint32_t)c1, kb);
-    float cv, cp;
-    if (cache_probe(d, s0, s1, lane, cv, cp)) return;   // already known
-    if (lane == 0) {
-        d.cold->spec_c0[g] = s0;
-        d.cold->spec_c1[g] = s1;
-        d.cold->spec_state[g] = 1;
-    }
-}
-
 template <typename T>
 __device__ __forceinline__ void store_plane(void *planes, size_t idx, float v);
 template <> __device__ __forceinline__ void store_plane<float>(void *p, size_t i, float v) { ((float *)p)[i] = v; }
@@ -442,7 +411,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
                                           const void *__restrict__ values_in,
                                           const void *__restrict__ priors_in, void *__restrict__ planes_out,
                                           uint64_t *leaf_out, SlotMem *sm = nullptr, const int ai_lds = 0,
-                                          const int si_lds = 0)
+                                          uint32_t *wg_stats = nullptr)
 {
     if (leaf_out && lane < 2) leaf_out[lane] = 0;
     if (g >= d.slot_hi) return;
@@ -457,7 +426,6 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
     }
     constexpr bool SCORE_F32 = (EVAL == C4_EVAL_EXTERNAL_F32);
     const int ai = LDS_STATE ? ai_lds : g;            // row of the evaluator's answer for this slot
-    const int si = LDS_STATE ? si_lds : d.G + g;      // row of the answer to its speculative request
 
     const Pool pool{d.pool + (size_t)g * d.cap * (BLOCK_BYTES / 8)};
     PathEntry *gpath = d.path + (size_t)g * MAX_DEPTH;
@@ -508,21 +476,6 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
     stamp(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(1);
-    // speculative answer from the previous network pass: into the cache, then look one ply further
-    if (EVAL == C4_EVAL_EXTERNAL_F32 && d.speculate && d.cache && d.cold->spec_state[g] == 2) {
-        const uint64_t q0 = d.cold->spec_c0[g], q1 = d.cold->spec_c1[g];
-        const float sv = ((const float *)values_in)[si];
-        const float sp = lane < 7 ? ((const float *)priors_in)[(size_t)si * 7 + lane] : 0.0f;
-        if (lane == 0) d.cold->spec_state[g] = 0;
-        const bool okv = sv >= 0.0f && sv <= 1.0f && sp >= 0.0f && sp <= 3.0e38f;
-        if (!((__ballot(!okv) >> (((threadIdx.x & 63) / GROUP) * GROUP)) & 0xffull)) {
-            cache_insert(d, q0, q1, lane, sv, sp);
-            const int qm = legal_mask(q0 | q1);
-            const bool ql = lane < 7 && ((qm >> lane) & 1);
-            spec_request(d, g, lane, q0, q1, ql ? (double)sp : -1.0, ql);
-        }
-    }
-
     // A slot may walk at most `level_budget` descent levels per launch; a descent that runs out is
     // suspended (node, board and path are saved) and resumed by the next launch.  Every wave then
     // does about the same amount of work per launch instead of waiting for the deepest tree.
@@ -541,11 +494,9 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
         // ---------------------------------------------------------------- evaluate_node + expand + backup
         if (apply_now) {
             apply_now = false;
-            bool want_spec = false;
             if (fresh_eval) {   // evaluators.py:21-24: position_table[key] = evaluate_fn(board)
                 fresh_eval = false;
                 cache_insert(d, leaf0, leaf1, lane, (float)ev_value, (float)ev_prior);
-                want_spec = d.speculate != 0;
             }
             // The reference asserts that the net never answers NaN (model.py:258-263).  A NaN here would
             // poison every comparison of the argmax, so answers are made finite first: memory safety of
@@ -598,7 +549,6 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
                 prn = a + b;
                 pf64 = 1;
             }
-            if (want_spec) spec_request(d, g, lane, leaf0, leaf1, prn, legal);   // prn: the prior PUCT will see
             // tree.py:119-132: children in ascending column order, one 8-aligned block
             const uint32_t nchild = (uint32_t)__popc(mask);
             const uint32_t base = nalloc * GROUP;
@@ -973,9 +923,10 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
             sm->ply = ply;
             sm->gid = gid;
             sm->state = state;
-            const uint32_t *sv = (const uint32_t *)&st;
+            const uint32_t *sv = (const uint32_t *)&st;   // counters: per workgroup, flushed once per launch
 #pragma unroll
-            for (int i = 0; i < N_STATS; ++i) sm->stats[i] += sv[i];
+            for (int i = 0; i < N_STATS; ++i)
+                if (sv[i]) atomicAdd(&wg_stats[i], sv[i]);
         }
         return;
     }
@@ -1015,37 +966,39 @@ __global__ __launch_bounds__(BLOCK) void c4_step_kernel(Dev d, const void *__res
 }
 
 // ------------------------------------------------------------------------------------------
-// fused persistent self-play kernel: one workgroup = 16 slots = one CU-sized unit that alternates
-//   tree phase  (waves 0-1: the slots' 8-lane groups run tree_step)
-//   net phase   (all 8 waves: net_forward_block on the 16 leaves, straight from LDS)
+// fused persistent self-play kernel: one workgroup = TS slots = one CU-sized unit that alternates
+//   tree phase  (all 8 waves, TS/8 slots per wave in 8-lane groups, run tree_step)
+//   net phase   (all 8 waves: net_forward_block on the emitted leaves, 16 per pass, straight from LDS)
 // for n_steps rounds with NO kernel boundary, no inter-workgroup traffic and no global barrier:
-// a workgroup only ever waits for its own 16 trees, not for the deepest tree of the whole batch.
+// a workgroup only ever waits for its own trees, not for the deepest tree of the whole batch.
+// The tree phase is bound by the latency of dependent sibling-block loads, not by issue slots, so
+// more slots per wave cost it little while every network pass stays a full 16-position batch:
+// TS = 32 when the batch is large enough to give every CU such a workgroup, else 16.
 // ------------------------------------------------------------------------------------------
+template <int TS>
 __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4net::NetDev nd, float *__restrict__ values,
                                                                       float *__restrict__ priors, int n_steps)
 {
     using namespace c4net;
+    static_assert(TS % NWAVES == 0 && TS % P == 0 && TS <= 64, "slots per workgroup");
     __shared__ __attribute__((aligned(16))) _Float16 act[2][(ROWS + 1) * CS];
     __shared__ __attribute__((aligned(16))) half8 wbuf[2][WCHUNKS];
     __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
-    __shared__ uint64_t sleaf[2][P];   // leaf bitboards handed from the tree phase to the net phase (compacted)
-    __shared__ int smap[P];            // compacted row -> answer row
+    __shared__ uint64_t sleaf[2][TS];  // leaf bitboards handed from the tree phase to the net phase (compacted)
+    __shared__ int smap[TS];           // compacted row -> slot of the workgroup
     __shared__ int sn;                 // number of leaves this round
-    __shared__ SlotMem smem[P];        // the workgroup's slot states, LDS-resident for the whole launch
-    __shared__ float s_val[2 * P];     // network answers: rows 0..P-1 the slots' leaves, P.. their speculative requests
-    __shared__ float s_pri[2 * P * 7];
-    static_assert((sizeof(PathEntry) * MAX_DEPTH + sizeof(Rec) * GROUP) * P <= sizeof(_Float16) * ROWS * CS, "tree-phase LDS must fit the activation buffer");
+    __shared__ SlotMem smem[TS];       // the workgroup's slot states, LDS-resident for the whole launch
+    __shared__ float s_val[TS];        // network answers per slot
+    __shared__ float s_pri[TS * 7];
+    __shared__ uint32_t s_stats[N_STATS];   // counters of this launch (integer sums: order does not matter)
+    static_assert((sizeof(PathEntry) * MAX_DEPTH + sizeof(Rec) * GROUP) * TS <= sizeof(_Float16) * ROWS * CS, "tree-phase LDS must fit the activation buffer");
     // the tree phase's path stacks live in activation buffer 0, which the net overwrites afterwards
     PathEntry (*s_path)[MAX_DEPTH] = reinterpret_cast<PathEntry (*)[MAX_DEPTH]>(&act[0][0]);
-    Rec (*s_l1)[GROUP] = reinterpret_cast<Rec (*)[GROUP]>(&act[0][0] + sizeof(PathEntry) * MAX_DEPTH * P / sizeof(_Float16));
-    const int slot0 = blockIdx.x * P;
-    const int lane = threadIdx.x & (GROUP - 1);
-    // two slots per wave (lanes 0..15), all 8 waves busy: slots that sit in one wave execute in SIMT
-    // lock-step and wait for each other's deeper trees, so spreading them over waves shortens the phase
-    const int wv = threadIdx.x >> 6, grp = (threadIdx.x & 63) / GROUP;
-    const int sl = wv + NWAVES * grp;     // slot of this 8-lane group inside the workgroup (grp < 2)
+    Rec (*s_l1)[GROUP] = reinterpret_cast<Rec (*)[GROUP]>(&act[0][0] + sizeof(PathEntry) * MAX_DEPTH * TS / sizeof(_Float16));
+    const int slot0 = blockIdx.x * TS;
+    const int wv = threadIdx.x >> 6;
     // ---- launch prologue: slot states and the pending network answers, global -> LDS
-    if (threadIdx.x < P) {
+    if (threadIdx.x < TS) {
         const int p = threadIdx.x, g = slot0 + p;
         SlotMem m = {};
         m.state = SLOT_PARKED;
@@ -1057,30 +1010,39 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
         }
         smem[p] = m;
     }
-    for (int i = threadIdx.x; i < 2 * P * 8; i += NTHREADS) {   // answers of the previous launch (+ speculative rows)
-        const int row = i >> 3, k = i & 7, p = row % P;
-        const int src = (row < P ? 0 : d.G) + slot0 + p;
-        const bool ok = slot0 + p < d.G && (row < P || d.speculate);
-        if (k == 7) s_val[row] = ok ? values[src] : 0.0f;
-        else s_pri[row * 7 + k] = ok ? priors[(size_t)src * 7 + k] : 0.0f;
+    if (threadIdx.x < N_STATS) s_stats[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < TS * 8; i += NTHREADS) {   // answers of the previous launch
+        const int p = i >> 3, k = i & 7;
+        const bool ok = slot0 + p < d.G;
+        if (k == 7) s_val[p] = ok ? values[slot0 + p] : 0.0f;
+        else s_pri[p * 7 + k] = ok ? priors[(size_t)(slot0 + p) * 7 + k] : 0.0f;
     }
     __syncthreads();
     unsigned long long t_tree = 0, t_net = 0, t_own = 0;   // diagnostic (C4_TREE_STAMPS=1)
     for (int step = 0; step < n_steps; ++step) {
         const unsigned long long ta = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
-        if (grp < P / NWAVES)
+        // The thread id is laundered once per step: everything the tree phase derives from it (LDS and
+        // pool addresses) is then recomputed here instead of being hoisted out of the step loop, where it
+        // would stay live across the network phase (which needs every VGPR) and be spilled to scratch.
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & (GROUP - 1);
+        // slots that sit in one wave execute in SIMT lock-step, so consecutive slots go to different waves
+        const int grp = (tid & 63) / GROUP;
+        const int sl = (tid >> 6) + NWAVES * grp;     // slot of this 8-lane group inside the workgroup
+        if (grp < TS / NWAVES)
             tree_step<C4_EVAL_EXTERNAL_F32, false, true>(d, slot0 + sl, lane, sl, s_path, s_l1, s_val, s_pri, nullptr, nullptr,
-                                                         &smem[sl], sl, P + sl);
+                                                         &smem[sl], sl, s_stats);
         const unsigned long long tb = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
         __syncthreads();   // slot states (LDS) are visible to the whole workgroup
         const unsigned long long tc = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
         t_own += tb - ta;
         t_tree += tc - ta;
-        // compact the leaves: only slots that emitted one (cache miss) take a row of the network's batch;
-        // the network skips the tiles beyond the last real row
+        // compact the leaves: only slots that emitted one (cache miss) take a row of a network pass;
+        // a pass skips the tiles beyond its last real row, and passes without any row are skipped
         if (threadIdx.x < 64) {
             const int p = threadIdx.x;
-            const bool has = p < P && smem[p < P ? p : 0].has_leaf != 0;
+            const bool has = p < TS && smem[p < TS ? p : 0].has_leaf != 0;
             const unsigned long long m = __ballot(has);
             if (has) {
                 const int j = __popcll(m & ((1ULL << p) - 1));
@@ -1088,45 +1050,33 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
                 sleaf[1][j] = smem[p].leaf1;
                 smap[j] = p;
             }
-            const int k = __popcll(m);
-            // spare rows: speculative requests (answers go to rows P + slot)
-            const bool sp = d.speculate && p < P && slot0 + p < d.G && d.cold->spec_state[slot0 + p] == 1;
-            const unsigned long long ms = __ballot(sp);
-            int ns = 0;
-            if (sp) {
-                const int j = k + __popcll(ms & ((1ULL << p) - 1));
-                if (j < P) {
-                    sleaf[0][j] = d.cold->spec_c0[slot0 + p];
-                    sleaf[1][j] = d.cold->spec_c1[slot0 + p];
-                    smap[j] = P + p;
-                    d.cold->spec_state[slot0 + p] = 2;
-                }
-            }
-            ns = min(P - k, (int)__popcll(ms));
-            if (p == 0) sn = k + ns;
+            if (p == 0) sn = __popcll(m);
         }
         __syncthreads();
-        net_forward_block(nd, NetLds{act, wbuf, mlp}, sleaf[0], sleaf[1], sn, 0, s_val, s_pri, smap);
+        const int nleaf = sn;
+        for (int r0 = 0; r0 < nleaf; r0 += P) {
+            if (r0) __syncthreads();   // the previous pass has read its inputs and written its answers
+            net_forward_block(nd, NetLds{act, wbuf, mlp}, sleaf[0] + r0, sleaf[1] + r0, min(P, nleaf - r0), 0, s_val, s_pri,
+                              smap + r0);
+        }
         __syncthreads();   // answers written; LDS free for the next tree phase
         if (d.has_stamps) t_net += __builtin_amdgcn_s_memtime() - tc;
     }
     // ---- launch epilogue: LDS -> global (the next launch, c4_step, read-outs and the host see the Dev arrays)
-    if (threadIdx.x < P && slot0 + threadIdx.x < d.G) {
+    if (threadIdx.x < TS && slot0 + threadIdx.x < d.G) {
         const int p = threadIdx.x, g = slot0 + p;
         const SlotMem m = smem[p];
         d.root_c0[g] = m.root0; d.root_c1[g] = m.root1; d.leaf_c0[g] = m.leaf0; d.leaf_c1[g] = m.leaf1;
         d.game_id[g] = m.gid; d.sims_done[g] = m.sims; d.n_alloc[g] = m.nalloc; d.pending[g] = m.pend;
         d.pending_depth[g] = m.pdepth; d.pending_info[g] = m.pinfo; d.need_root[g] = m.need_root;
         d.ply[g] = m.ply; d.state[g] = m.state; d.has_leaf[g] = m.has_leaf;
-        uint64_t *sp = d.stats + (size_t)g * N_STATS;
-        for (int i = 0; i < N_STATS; ++i) sp[i] += m.stats[i];
     }
-    for (int i = threadIdx.x; i < 2 * P * 8; i += NTHREADS) {
-        const int row = i >> 3, k = i & 7, p = row % P;
-        const int dst = (row < P ? 0 : d.G) + slot0 + p;
-        if (slot0 + p < d.G && (row < P || d.speculate)) {
-            if (k == 7) values[dst] = s_val[row];
-            else priors[(size_t)dst * 7 + k] = s_pri[row * 7 + k];
+    if (threadIdx.x < N_STATS) d.stats[(size_t)slot0 * N_STATS + threadIdx.x] += s_stats[threadIdx.x];   // the workgroup's row
+    for (int i = threadIdx.x; i < TS * 8; i += NTHREADS) {
+        const int p = i >> 3, k = i & 7;
+        if (slot0 + p < d.G) {
+            if (k == 7) values[slot0 + p] = s_val[p];
+            else priors[(size_t)(slot0 + p) * 7 + k] = s_pri[p * 7 + k];
         }
     }
     if (d.has_stamps && blockIdx.x < 128 && (threadIdx.x & 63) == 0) {   // rows 2b: per-wave own tree work, 2b+1: phases
@@ -1149,7 +1099,6 @@ __global__ void c4_reset_kernel(Dev d, const uint64_t *c0, const uint64_t *c1, i
     d.leaf_c0[g] = 0;
     d.leaf_c1[g] = 0;
     d.has_leaf[g] = 0;
-    d.cold->spec_state[g] = 0;
     d.pending[g] = -1;
     d.pending_depth[g] = 0;
     d.pending_info[g] = 0;
@@ -1269,6 +1218,7 @@ struct c4_engine {
     std::vector<void *> allocs;
     std::vector<long long> drained_tag;   // per ring slot: game id already handed out (-1 none)
     int64_t launches;
+    int fused_slots;      // slots per workgroup of the fused self-play kernel (16 or 32)
     int tape_games;
     double *tape_noise, *tape_u;
     char err[512];
@@ -1379,6 +1329,15 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     e->device = device;
     e->stream = nullptr;
     e->launches = 0;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+        e->fused_slots = ((cfg->n_slots + 31) / 32 >= cus) ? 32 : 16;
+        if (const char *fs = getenv("C4_FUSED_SLOTS")) {   // tuning aid: force 16 or 32
+            const int v = atoi(fs);
+            if (v == 16 || v == 32) e->fused_slots = v;
+        }
+    }
     e->tape_games = 0;
     e->tape_noise = nullptr;
     e->tape_u = nullptr;
@@ -1403,7 +1362,6 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
                                             : (cfg->eval_mode == C4_EVAL_CENTRE ? 1 << 20 : 1);
     d.level_budget = cfg->level_budget > 0 ? cfg->level_budget : 0;
     d.time_budget = cfg->time_budget_cycles > 0 ? cfg->time_budget_cycles : 0;
-    d.speculate = cfg->speculate ? 1 : 0;
     d.planes_dtype = cfg->planes_dtype;
     d.games_target = cfg->games_target;
     d.seed = cfg->seed;
@@ -1425,7 +1383,6 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     ALLOC(d.stats, G * N_STATS);
     ALLOC(e->cold.res_move, G); ALLOC(e->cold.res_value, G); ALLOC(e->cold.res_policy, G * 7);
     ALLOC(e->cold.next_game, 1);
-    ALLOC(e->cold.spec_c0, G); ALLOC(e->cold.spec_c1, G); ALLOC(e->cold.spec_state, G);
     const size_t R = (size_t)d.rec_cap;
     ALLOC(e->cold.rec_c0, R * 42); ALLOC(e->cold.rec_c1, R * 42); ALLOC(e->cold.rec_move, R * 42);
     ALLOC(e->cold.rec_value, R * 42); ALLOC(e->cold.rec_policy, R * 42 * 7);
@@ -1585,13 +1542,17 @@ int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *prior
 {
     if (!e || !net || !values_dev || !priors_dev || n_steps <= 0) { if (e) set_err(e->err, "c4_selfplay_steps: bad argument"); return C4_EINVAL; }
     if (e->cfg.eval_mode != C4_EVAL_EXTERNAL_F32) { set_err(e->err, "c4_selfplay_steps needs C4_EVAL_EXTERNAL_F32"); return C4_ESTATE; }
-    if (e->d.G % c4net::P) { set_err(e->err, "c4_selfplay_steps needs n_slots to be a multiple of %d", c4net::P); return C4_EINVAL; }
     if (net->device != e->device) { set_err(e->err, "engine and net live on different devices"); return C4_EINVAL; }
     if (e->d.rng_tape && (e->d.use_noise || e->d.nsm > 0) && !e->cold.noise_tape) { set_err(e->err, "C4_RNG_TAPE engine needs c4_set_tapes before stepping"); return C4_ESTATE; }
     c4net::NetDev nd = net->d;
     nd.stamps = nullptr;
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
-    hipLaunchKernelGGL(c4_selfplay_kernel, dim3(e->d.G / c4net::P), dim3(c4net::NTHREADS), 0, st, e->d, nd, values_dev, priors_dev, (int)n_steps);
+    // 32 slots per workgroup once that still gives every CU a workgroup (the tree phase is latency bound,
+    // so its cost is shared by twice the slots); smaller batches keep 16 so that no CU stays idle
+    if (e->fused_slots == 32)
+        hipLaunchKernelGGL(c4_selfplay_kernel<32>, dim3((e->d.G + 31) / 32), dim3(c4net::NTHREADS), 0, st, e->d, nd, values_dev, priors_dev, (int)n_steps);
+    else
+        hipLaunchKernelGGL(c4_selfplay_kernel<16>, dim3((e->d.G + 15) / 16), dim3(c4net::NTHREADS), 0, st, e->d, nd, values_dev, priors_dev, (int)n_steps);
     HIPCHK(e, hipGetLastError());
     e->launches += n_steps;
     return C4_OK;

@@ -25,7 +25,7 @@ class Engine:
                  root_dirichlet_alpha=0.0, root_exploration_fraction=0.0, num_sampling_moves=0,
                  eval_mode=L.EVAL_EXTERNAL_F32, rng_mode=L.RNG_PHILOX, seed=0, stop_after_move=False,
                  games_target=-1, record_capacity_games=0, max_inner_iters=0,
-                 planes_dtype=L.PLANES_F32, eval_cache_log2_entries=0, level_budget=0, time_budget_cycles=0, speculate=False, device=0):
+                 planes_dtype=L.PLANES_F32, eval_cache_log2_entries=0, level_budget=0, time_budget_cycles=0, device=0):
         self._lib = L.load()
         self.cfg = L.Config()
         self.cfg.abi_version = L.ABI_VERSION
@@ -47,7 +47,6 @@ class Engine:
         self.cfg.eval_cache_log2_entries = int(eval_cache_log2_entries)
         self.cfg.level_budget = int(level_budget)
         self.cfg.time_budget_cycles = int(time_budget_cycles)
-        self.cfg.speculate = 1 if speculate else 0
         self.n_slots = int(n_slots)
         self.device = int(device)
         self._h = C.c_void_p()

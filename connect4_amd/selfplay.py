@@ -27,21 +27,19 @@ class SelfPlay:
                  games_target: int = -1, record_capacity_games: int = 0, planes_dtype=torch.float32,
                  use_graph: bool = True, steps_per_graph: int = 8, max_inner_iters: int = 32,
                  eval_cache_log2_entries: int = 0, level_budget: int = 0, time_budget_cycles: int = 80000, pipeline: int = 1,
-                 fused_loop: bool = False, steps_per_launch: int = 32, speculate: bool = False):
+                 fused_loop: bool = False, steps_per_launch: int = 32):
         self.net = net
         self.n_slots = n_slots
         self.config = config
         self.device = torch.device("cuda", device)
-        spec = bool(speculate and fused_loop and getattr(net, "from_bitboards", False) and n_slots % 16 == 0)
-        self.engine = Engine(n_slots, eval_mode=L.EVAL_EXTERNAL_F32, speculate=spec, rng_mode=L.RNG_PHILOX, seed=seed,
+        self.engine = Engine(n_slots, eval_mode=L.EVAL_EXTERNAL_F32, rng_mode=L.RNG_PHILOX, seed=seed,
                              stop_after_move=False, games_target=games_target,
                              record_capacity_games=record_capacity_games, max_inner_iters=max_inner_iters,
                              planes_dtype=_PLANES[planes_dtype], eval_cache_log2_entries=eval_cache_log2_entries, level_budget=level_budget, time_budget_cycles=time_budget_cycles,
                              device=device, **config.engine_kwargs())
         with torch.cuda.device(self.device):
-            rows = 2 * n_slots if spec else n_slots     # second half: speculative answers
-            self.values = torch.zeros(rows, dtype=torch.float32, device=self.device)
-            self.priors = torch.full((rows, 7), 1.0 / 7.0, dtype=torch.float32, device=self.device)
+            self.values = torch.zeros(n_slots, dtype=torch.float32, device=self.device)
+            self.priors = torch.full((n_slots, 7), 1.0 / 7.0, dtype=torch.float32, device=self.device)
             self.planes = torch.zeros(n_slots, 3, 6, 7, dtype=planes_dtype, device=self.device)
         self._bits = bool(getattr(net, "from_bitboards", False))   # fused kernel reads the leaf bitboards
         # pipeline=2: the batch is split in two halves on two HIP streams, phase-shifted, so the
@@ -49,7 +47,7 @@ class SelfPlay:
         self._pipeline = 2 if (pipeline == 2 and self._bits and n_slots % 16 == 0) else 1
         self._streams = None
         # fused_loop: tree step + network in ONE persistent kernel (c4_selfplay_steps), no graph needed
-        self._fused_loop = bool(fused_loop and self._bits and n_slots % 16 == 0)
+        self._fused_loop = bool(fused_loop and self._bits)
         self._steps_per_launch = max(1, steps_per_launch)
         self._leaf_c0, self._leaf_c1, _ = self.engine.leaf_buffers()
         self.steps_done = 0

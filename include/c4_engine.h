@@ -94,12 +94,7 @@ typedef struct {
                                           has run this many shader cycles (balances the waves of a launch by
                                           cost instead of by count; which launch runs a simulation never
                                           changes results).  0 = off */
-    int32_t speculate;                 /* fused self-play only: queue the most probable child of every
-                                          network-evaluated leaf for the spare rows of the network's batch;
-                                          answers only enter the evaluation cache (results unchanged).
-                                          values_dev / priors_dev of c4_selfplay_steps must then hold
-                                          2*n_slots rows (second half = speculative answers) */
-    int32_t reserved[3];
+    int32_t reserved[4];               /* must be 0 */
 } c4_config;
 
 typedef struct c4_engine c4_engine;
@@ -254,12 +249,13 @@ int c4_net_forward(c4_net *net, void *hip_stream, const uint64_t *color0_dev, co
                    int32_t n, float *values_dev, float *priors_dev);
 const char *c4_net_last_error(void);
 
-/* Fused persistent self-play: n_steps rounds of {c4_step for 16 slots; c4_net_forward on their 16
- * leaves} per workgroup in ONE launch -- no kernel boundary, no global barrier, a workgroup waits only
- * for its own 16 trees.  Same results as alternating c4_step / c4_net_forward.  values_dev float32
- * [n_slots], priors_dev float32 [n_slots][7] are the hand-off buffers (must persist between calls; twice
- * as many rows when c4_config.speculate is set).
- * Needs C4_EVAL_EXTERNAL_F32 and n_slots % 16 == 0. */
+/* Fused persistent self-play: n_steps rounds of {c4_step for the workgroup's 32 slots; c4_net_forward
+ * on the leaves they emitted, 16 per pass} in ONE launch -- no kernel boundary, no global barrier, a
+ * workgroup waits only for its own trees; slot state, leaves and answers stay in LDS between the
+ * rounds.  Same results as alternating c4_step / c4_net_forward.  values_dev float32 [n_slots],
+ * priors_dev float32 [n_slots][7] are the hand-off buffers (must persist between calls).
+ * Needs C4_EVAL_EXTERNAL_F32.  Per-slot rows of the statistics are only exact per workgroup after
+ * this call (c4_get_stats sums them; the sums are exact). */
 int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *priors_dev, int32_t n_steps,
                       void *hip_stream);
 /* diagnostic build aid: per-phase s_memtime stamps of workgroup 0, [8 waves][16]; needs the
@@ -267,7 +263,9 @@ int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *prior
 int c4_net_debug_stamps(c4_net *net, unsigned long long *out);
 
 /* diagnostic build aid: per-phase s_memtime stamps of the last c4_step launch, [256 workgroups][8]
- * (0 start, 1 slot state loaded, 2 apply done, 3 descent done, 4 before emit, 5 end, 6 depth);
+ * (0 start, 1 slot state loaded, 2 apply done, 3 descent done, 4 before emit, 5 end, 6 depth), or of
+ * the last c4_selfplay_steps launch, [128 workgroups][16] (0-7 tree-phase cycles of each wave, 8 tree
+ * phase incl. barrier, 9 network phase, 10 steps);
  * needs C4_TREE_STAMPS=1 in the environment when the engine is created, else C4_ESTATE. */
 int c4_debug_stamps(c4_engine *e, unsigned long long *out);
 

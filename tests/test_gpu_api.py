@@ -168,7 +168,7 @@ def test_match_lockstep_equals_sequential_oracle(oracle):
     assert (out["wins"], out["draws"], out["losses"]) == (wins, draws, losses)
 
 
-def test_fused_selfplay_kernel_equals_separate_kernels():
+def test_fused_selfplay_kernel_equals_separate_kernels(monkeypatch):
     """c4_selfplay_steps (tree step + network in one persistent kernel) must play exactly the games
     that alternating c4_step / c4_net_forward plays (same seed => same games, id by id)."""
     from connect4_amd.config import MCTSConfig
@@ -178,9 +178,10 @@ def test_fused_selfplay_kernel_equals_separate_kernels():
     net = FusedNet(random_init_state_dict(seed=0))
     cfg = MCTSConfig.self_play(48)
     out = []
-    for fused in (False, True):   # the fused run also speculates (answers only enter the cache)
-        sp = SelfPlay(net, 64, cfg, seed=11, games_target=96, record_capacity_games=96, use_graph=False,
-                      fused_loop=fused, steps_per_launch=16, max_inner_iters=3, speculate=True)
+    for fused in (0, 16, 32):   # separate kernels; fused with 16 / 32 slots per workgroup (72 slots: ragged last workgroup)
+        monkeypatch.setenv("C4_FUSED_SLOTS", str(fused or 16))
+        sp = SelfPlay(net, 72, cfg, seed=11, games_target=96, record_capacity_games=96, use_graph=False,
+                      fused_loop=bool(fused), steps_per_launch=16, max_inner_iters=3)
         for _ in range(400):
             sp.run_steps(64)
             if sp.stats()["active_slots"] == 0:
@@ -190,10 +191,12 @@ def test_fused_selfplay_kernel_equals_separate_kernels():
         sp.close()
         assert len(games) == 96
         out.append(([(g.game_id, g.moves, g.result.value, g.values, [list(p) for p in g.priors]) for g in games], st))
-    assert out[0][0] == out[1][0]
-    for k in ("simulations", "expansions", "moves", "games_finished", "terminal_sims"):
-        assert out[0][1][k] == out[1][1][k]
-    assert out[0][1]["bad_evals"] == 0 and out[1][1]["bad_evals"] == 0   # the net never answers NaN
+    for other in out[1:]:
+        assert out[0][0] == other[0]
+        for k in ("simulations", "expansions", "moves", "games_finished", "terminal_sims"):
+            assert out[0][1][k] == other[1][k]
+        assert other[1]["bad_evals"] == 0   # the net never answers NaN
+    assert out[0][1]["bad_evals"] == 0
 
 
 def test_mini_generation_selfplay_train_reload(tmp_path):

@@ -114,13 +114,18 @@ constexpr int N_STATS = sizeof(SlotStats) / sizeof(uint64_t);
 struct SlotMem {
     uint64_t root0, root1, leaf0, leaf1;
     long long gid;
+    double root_w;             // W of the root node (its N is sims + 1, its info follows from the root board)
     uint32_t sims, nalloc;
     int32_t pend;
     uint32_t pdepth, pinfo;
-    int32_t need_root;
     uint32_t ply;
-    int32_t state, has_leaf;
+    uint32_t flags;            // state | has_leaf << 8 | need_root << 16
+    __device__ int state() const { return (int)(flags & 0xffu); }
+    __device__ bool has_leaf() const { return ((flags >> 8) & 0xffu) != 0; }
+    __device__ int need_root() const { return (int)(flags >> 16); }
+    __device__ static uint32_t pack(int state, int has_leaf, int need_root) { return (uint32_t)state | ((uint32_t)has_leaf << 8) | ((uint32_t)need_root << 16); }
 };
+static_assert(sizeof(SlotMem) == 80, "32 of these must fit the fused kernel's LDS budget");
 
 // Rarely touched pointers (move choice, game end, suspended descents, diagnostics) live in device
 // memory behind one pointer: a kernel argument block with ~60 pointers does not fit the scalar
@@ -416,8 +421,8 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
     if (leaf_out && lane < 2) leaf_out[lane] = 0;
     if (g >= d.slot_hi) return;
     if (LDS_STATE) {
-        if (sm->state != SLOT_ACTIVE) {
-            if (lane == 0) sm->has_leaf = 0;
+        if (sm->state() != SLOT_ACTIVE) {
+            if (lane == 0) sm->flags = SlotMem::pack(sm->state(), 0, sm->need_root());
             return;
         }
     } else if (d.state[g] != SLOT_ACTIVE) {
@@ -438,12 +443,13 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
     if (LDS_STATE) {
         root0 = sm->root0; root1 = sm->root1;
         sims = sm->sims; nalloc = sm->nalloc; pend = sm->pend; pdepth = sm->pdepth; pinfo = sm->pinfo;
-        need_root = sm->need_root; ply = sm->ply; gid = sm->gid;
+        need_root = sm->need_root(); ply = sm->ply; gid = sm->gid;
     } else {
         root0 = d.root_c0[g]; root1 = d.root_c1[g];
         sims = d.sims_done[g]; nalloc = d.n_alloc[g]; pend = d.pending[g]; pdepth = d.pending_depth[g];
         pinfo = d.pending_info[g]; need_root = d.need_root[g]; ply = d.ply[g]; gid = d.game_id[g];
     }
+    double root_w = LDS_STATE ? sm->root_w : 0.0;   // LDS mode: the root record is never re-read (see the descent)
     int state = SLOT_ACTIVE;
     int has_leaf = 0;
     struct { uint32_t sims, expansions, children, terminal_sims, leaf_evals, depth_sum, moves, games_started,
@@ -583,6 +589,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
                 pool.q(e.node) = nq;
                 if (l1_valid && i == 1) { Rec &c = s_l1[gl][e.node & 7]; c.n = e.n + 1; c.w = nw; c.q = nq; }
             }
+            root_w = pdepth == 0 ? ev_value : root_w + ev_value;
             if (pdepth == 0) l1_valid = false;   // a new sibling block under the root
             st.leaf_evals += 1;
             st.children += nchild;
@@ -757,10 +764,19 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
             for (uint32_t i = lane; i <= depth; i += GROUP) s_path[gl][i] = gpath[i];
             pend = -1;
         } else {
-            const Rec rr = *pool.rec(0);
-            cinfo = rr.info;
-            cN = rr.n;
-            cW = rr.w;
+            if (LDS_STATE) {
+                // the root record is implied by the slot state: N = completed simulations + 1 (mcts.py:132-134,
+                // :164-168), W is carried along, and its children are the first block of the fresh tree
+                cinfo = pack_info(GROUP, (uint32_t)__popc(legal_mask(root0 | root1)), ST_EVALUATED, 0,
+                                  (!SCORE_F32 || d.use_noise) ? 1u : 0u);
+                cN = sims + 1;
+                cW = root_w;
+            } else {
+                const Rec rr = *pool.rec(0);
+                cinfo = rr.info;
+                cN = rr.n;
+                cW = rr.w;
+            }
             b0 = root0;
             b1 = root1;
             if (lane == 0) s_path[gl][0] = PathEntry{0u, cN, cW};
@@ -773,6 +789,10 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
             if (cN == 1) st.expansions += 1;   // first descent through an evaluated node == expand_node
             const bool act = lane < (int)nc;
             const uint32_t idx = cb + lane;
+            // the score-table entry is requested FIRST so that its (L1/L2) latency hides under the
+            // sibling-block loads instead of being paid after them; the barrier keeps the order
+            const double2 ab = d.tabAB[cN];
+            asm volatile("" ::: "memory");
             Rec r = {};
             if (depth == 0 && l1_valid) {
                 if (act) r = s_l1[gl][lane];                  // hot subtree: LDS
@@ -785,7 +805,6 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
             }
             const uint32_t n = r.n, inf = r.info;
             const double w = r.w, q = r.q, p = r.p;
-            const double2 ab = d.tabAB[cN];
             const double A = ab.x, B = ab.y;
             if (STAMPS && d.has_stamps) {   // diagnostic: cycles spent waiting for this level's loads
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -850,6 +869,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
                 pool.q(e.node) = nq;
                 if (l1_valid && i == 1) { Rec &c = s_l1[gl][e.node & 7]; c.n = e.n + 1; c.w = nw; c.q = nq; }
             }
+            root_w = root_w + value;
             sims += 1;
             st.sims += 1;
             st.terminal_sims += 1;
@@ -911,7 +931,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
         // node records, cache lines and game records drain in the background: only this group reads
         // them back, and a wave's own memory operations stay in order
         if (lane == 0) {
-            sm->has_leaf = has_leaf;
+            sm->root_w = root_w;
             sm->root0 = root0;
             sm->root1 = root1;
             sm->sims = sims;
@@ -919,10 +939,9 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
             sm->pend = (has_leaf || pend == -2) ? pend : -1;
             sm->pdepth = pdepth;
             sm->pinfo = pinfo;
-            sm->need_root = need_root;
             sm->ply = ply;
             sm->gid = gid;
-            sm->state = state;
+            sm->flags = SlotMem::pack(state, has_leaf, need_root);
             const uint32_t *sv = (const uint32_t *)&st;   // counters: per workgroup, flushed once per launch
 #pragma unroll
             for (int i = 0; i < N_STATS; ++i)
@@ -1001,12 +1020,13 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
     if (threadIdx.x < TS) {
         const int p = threadIdx.x, g = slot0 + p;
         SlotMem m = {};
-        m.state = SLOT_PARKED;
+        m.flags = SlotMem::pack(SLOT_PARKED, 0, 0);
         if (g < d.G) {
             m.root0 = d.root_c0[g]; m.root1 = d.root_c1[g]; m.leaf0 = d.leaf_c0[g]; m.leaf1 = d.leaf_c1[g];
             m.gid = d.game_id[g]; m.sims = d.sims_done[g]; m.nalloc = d.n_alloc[g]; m.pend = d.pending[g];
-            m.pdepth = d.pending_depth[g]; m.pinfo = d.pending_info[g]; m.need_root = d.need_root[g];
-            m.ply = d.ply[g]; m.state = d.state[g]; m.has_leaf = d.has_leaf[g];
+            m.pdepth = d.pending_depth[g]; m.pinfo = d.pending_info[g];
+            m.ply = d.ply[g]; m.flags = SlotMem::pack(d.state[g], d.has_leaf[g], d.need_root[g]);
+            m.root_w = *(const double *)(d.pool + (size_t)g * d.cap * (BLOCK_BYTES / 8));   // Rec::w of node 0
         }
         smem[p] = m;
     }
@@ -1042,7 +1062,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
         // a pass skips the tiles beyond its last real row, and passes without any row are skipped
         if (threadIdx.x < 64) {
             const int p = threadIdx.x;
-            const bool has = p < TS && smem[p < TS ? p : 0].has_leaf != 0;
+            const bool has = p < TS && smem[p < TS ? p : 0].has_leaf();
             const unsigned long long m = __ballot(has);
             if (has) {
                 const int j = __popcll(m & ((1ULL << p) - 1));
@@ -1068,8 +1088,8 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
         const SlotMem m = smem[p];
         d.root_c0[g] = m.root0; d.root_c1[g] = m.root1; d.leaf_c0[g] = m.leaf0; d.leaf_c1[g] = m.leaf1;
         d.game_id[g] = m.gid; d.sims_done[g] = m.sims; d.n_alloc[g] = m.nalloc; d.pending[g] = m.pend;
-        d.pending_depth[g] = m.pdepth; d.pending_info[g] = m.pinfo; d.need_root[g] = m.need_root;
-        d.ply[g] = m.ply; d.state[g] = m.state; d.has_leaf[g] = m.has_leaf;
+        d.pending_depth[g] = m.pdepth; d.pending_info[g] = m.pinfo; d.need_root[g] = m.need_root();
+        d.ply[g] = m.ply; d.state[g] = m.state(); d.has_leaf[g] = m.has_leaf() ? 1 : 0;
     }
     if (threadIdx.x < N_STATS) d.stats[(size_t)slot0 * N_STATS + threadIdx.x] += s_stats[threadIdx.x];   // the workgroup's row
     for (int i = threadIdx.x; i < TS * 8; i += NTHREADS) {

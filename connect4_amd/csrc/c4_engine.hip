@@ -315,7 +315,9 @@ __device__ __forceinline__ int group_argmax(double s, int k)
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+    // bound_ctrl with full row/bank masks: every lane has a valid source in these permutations, and the
+    // compiler then needs no "old value" register initialised in front of each v_mov_b32_dpp
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v)
@@ -330,25 +332,43 @@ struct Pick {      // a candidate child with its record riding along
     uint32_t n, info;
     double w;
 };
+// One butterfly step.  Score and index are exchanged with v_mov_b32_dpp and compared; the record
+// fields that only ride along are selected with v_cndmask_b32_dpp (own value where VCC, else the
+// partner's, permuted inside the select), one instruction per field instead of mov_dpp + cndmask.
+// keep-own = (s > os) | (s == os & k >= ok): ties go to the higher column (tree.py:11-15).
+// DPP hazard: 2 wait states between the VALU write of a source and its DPP read -- s_mov + s_nop.
+#define C4_DPP_SELECT(CTRL)                                                                              \
+    asm volatile("s_mov_b64 vcc, %[m]\n"                                                                 \
+                 "s_nop 0\n"                                                                             \
+                 "v_cndmask_b32_dpp %[n], %[n], %[n], vcc " CTRL " row_mask:0xf bank_mask:0xf\n"         \
+                 "v_cndmask_b32_dpp %[i], %[i], %[i], vcc " CTRL " row_mask:0xf bank_mask:0xf\n"         \
+                 "v_cndmask_b32_dpp %[wl], %[wl], %[wl], vcc " CTRL " row_mask:0xf bank_mask:0xf\n"      \
+                 "v_cndmask_b32_dpp %[wh], %[wh], %[wh], vcc " CTRL " row_mask:0xf bank_mask:0xf\n"      \
+                 : [n] "+v"(n), [i] "+v"(info), [wl] "+v"(wl), [wh] "+v"(wh)                              \
+                 : [m] "s"(m)                                                                             \
+                 : "vcc")
 template <int CTRL>
-__device__ __forceinline__ void pick_step(Pick &a)
+__device__ __forceinline__ void pick_step(double &s, int &k, uint32_t &n, uint32_t &info, uint32_t &wl, uint32_t &wh)
 {
-    const double os = dpp_f64<CTRL>(a.s);
-    const int ok = (int)dpp_u32<CTRL>((uint32_t)a.k);
-    const uint32_t on = dpp_u32<CTRL>(a.n), oi = dpp_u32<CTRL>(a.info);
-    const double ow = dpp_f64<CTRL>(a.w);
-    const bool take = (os > a.s) | ((os == a.s) & (ok > a.k));   // ties -> higher column (tree.py:11-15)
-    a.s = take ? os : a.s;
-    a.k = take ? ok : a.k;
-    a.n = take ? on : a.n;
-    a.info = take ? oi : a.info;
-    a.w = take ? ow : a.w;
+    const double os = dpp_f64<CTRL>(s);
+    const int ok = (int)dpp_u32<CTRL>((uint32_t)k);
+    const bool keep = (s > os) | ((s == os) & (k >= ok));
+    s = keep ? s : os;
+    k = keep ? k : ok;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+    if (CTRL == 0xB1) C4_DPP_SELECT("quad_perm:[1,0,3,2]");
+    else if (CTRL == 0x4E) C4_DPP_SELECT("quad_perm:[2,3,0,1]");
+    else C4_DPP_SELECT("row_half_mirror");
 }
+#undef C4_DPP_SELECT
 __device__ __forceinline__ void group_pick(Pick &a)
 {
-    pick_step<0xB1>(a);    // quad_perm [1,0,3,2]
-    pick_step<0x4E>(a);    // quad_perm [2,3,0,1]
-    pick_step<0x141>(a);   // row_half_mirror
+    const uint64_t wb = (uint64_t)__double_as_longlong(a.w);
+    uint32_t wl = (uint32_t)wb, wh = (uint32_t)(wb >> 32);
+    pick_step<0xB1>(a.s, a.k, a.n, a.info, wl, wh);    // quad_perm [1,0,3,2]
+    pick_step<0x4E>(a.s, a.k, a.n, a.info, wl, wh);    // quad_perm [2,3,0,1]
+    pick_step<0x141>(a.s, a.k, a.n, a.info, wl, wh);   // row_half_mirror
+    a.w = __longlong_as_double((long long)(((uint64_t)wh << 32) | wl));
 }
 
 // ---- evaluation cache ------------------------------------------------------------------------

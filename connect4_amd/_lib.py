@@ -99,6 +99,7 @@ SIGNATURES = {
     "c4_net_create": (C.c_int, [C.c_int, _P(NetDesc), _P(C.c_void_p)]),
     "c4_net_destroy": (C.c_int, [C.c_void_p]),
     "c4_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "c4_net_forward_wave": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "c4_net_last_error": (C.c_char_p, []),
     "c4_selfplay_steps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "c4_net_debug_stamps": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),

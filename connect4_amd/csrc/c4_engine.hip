@@ -430,7 +430,9 @@ template <> __device__ __forceinline__ void store_plane<hip_bfloat16>(void *p, s
 // `sm` (fused kernel): the slot's state lives in LDS for the whole launch; the evaluator's answers are
 // then read at values_in[ai] / priors_in[ai*7..] (LDS as well).  Without `sm` the state is read from
 // and written to the Dev arrays and ai == g.
-template <int EVAL, bool STAMPS = true, bool LDS_STATE = false>
+// WAVE_SYNC (wave-autonomous fused kernel): the call ends as soon as any slot of this wave has left the
+// loop (it needs the evaluator, parked, ...), so the wave can evaluate that leaf right away.
+template <int EVAL, bool STAMPS = true, bool LDS_STATE = false, bool WAVE_SYNC = false>
 __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int lane, const int gl,
                                           PathEntry (*s_path)[MAX_DEPTH], Rec (*s_l1)[GROUP],
                                           const void *__restrict__ values_in,
@@ -516,6 +518,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
     // descent is an LDS read instead of an HBM round trip.
     bool l1_valid = false;
     int inner = 0;
+    const unsigned long long wave_mask0 = WAVE_SYNC ? __builtin_amdgcn_ballot_w64(true) : 0ull;
     for (;;) {
         // ---------------------------------------------------------------- evaluate_node + expand + backup
         if (apply_now) {
@@ -761,6 +764,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
         }
 
         // bound the launch: at most max_inner evaluator-free simulations per launch
+        if (WAVE_SYNC && !resume && __builtin_amdgcn_ballot_w64(true) != wave_mask0) break;   // a neighbour needs the network
         if (!resume && (inner >= d.max_inner || levels_left <= 0 ||
                         (d.time_budget > 0 && inner > 0 && (long long)(__builtin_amdgcn_s_memtime() - t_begin) > d.time_budget))) {
             st.capped += 1;
@@ -1127,6 +1131,120 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
 }
 
 // ------------------------------------------------------------------------------------------
+// wave-autonomous fused self-play kernel: like c4_selfplay_kernel, but there is no workgroup barrier
+// inside the step loop at all.  Every wave owns TS/8 slots and alternates
+//   tree_step for its slots until one of them needs the network (or max_inner simulations each),
+//   net_forward_wave on that wave's own leaves (two positions per pass, private LDS buffers),
+// so a tree never waits for the deepest tree of the workgroup or for a full 16-row batch: the answer
+// is there ~20 k cycles after the miss.  Same games as every other path (the network arithmetic is
+// bit-identical to net_forward_block's).
+// ------------------------------------------------------------------------------------------
+template <int TS>
+__global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(Dev d, c4net::NetDev nd, const c4net::NetDev *nd_dev,
+                                                                           float *__restrict__ values, float *__restrict__ priors,
+                                                                           int n_steps)
+{
+    using namespace c4net;
+    constexpr int SPW = TS / NWAVES;   // slots per wave
+    static_assert(TS % NWAVES == 0 && SPW >= 1 && SPW <= 8, "slots per workgroup");
+    __shared__ __attribute__((aligned(16))) _Float16 act[NWAVES][2][WACT];   // private activation buffers of the waves
+    __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
+    __shared__ SlotMem smem[TS];
+    __shared__ float s_val[TS];
+    __shared__ float s_pri[TS * 7];
+    __shared__ uint32_t s_stats[N_STATS];
+    static_assert((sizeof(PathEntry) * MAX_DEPTH + sizeof(Rec) * GROUP) * SPW <= sizeof(_Float16) * WACT, "a wave's path stacks must fit its activation buffer");
+    const int slot0 = blockIdx.x * TS;
+    const int wv = threadIdx.x >> 6;
+    // ---- launch prologue: slot states, pending answers and the MLP tables, global -> LDS
+    if (threadIdx.x < TS) {
+        const int p = threadIdx.x, g = slot0 + p;
+        SlotMem m = {};
+        m.flags = SlotMem::pack(SLOT_PARKED, 0, 0);
+        if (g < d.G) {
+            m.root0 = d.root_c0[g]; m.root1 = d.root_c1[g]; m.leaf0 = d.leaf_c0[g]; m.leaf1 = d.leaf_c1[g];
+            m.gid = d.game_id[g]; m.sims = d.sims_done[g]; m.nalloc = d.n_alloc[g]; m.pend = d.pending[g];
+            m.pdepth = d.pending_depth[g]; m.pinfo = d.pending_info[g];
+            m.ply = d.ply[g]; m.flags = SlotMem::pack(d.state[g], d.has_leaf[g], d.need_root[g]);
+            m.root_w = *(const double *)(d.pool + (size_t)g * d.cap * (BLOCK_BYTES / 8));   // Rec::w of node 0
+        }
+        smem[p] = m;
+    }
+    if (threadIdx.x < N_STATS) s_stats[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < TS * 8; i += NTHREADS) {   // answers of the previous launch
+        const int p = i >> 3, k = i & 7;
+        const bool ok = slot0 + p < d.G;
+        if (k == 7) s_val[p] = ok ? values[slot0 + p] : 0.0f;
+        else s_pri[p * 7 + k] = ok ? priors[(size_t)(slot0 + p) * 7 + k] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
+    __syncthreads();
+    Dev dw = d;
+    dw.time_budget = 0;   // a call ends when a slot of the wave blocks; max_inner bounds it
+    // the wave's path stacks and hot sibling blocks alias its first activation buffer (dead while the tree runs)
+    PathEntry (*s_path)[MAX_DEPTH] = reinterpret_cast<PathEntry (*)[MAX_DEPTH]>(&act[wv][0][0]);
+    Rec (*s_l1)[GROUP] = reinterpret_cast<Rec (*)[GROUP]>(&act[wv][0][0] + sizeof(PathEntry) * MAX_DEPTH * SPW / sizeof(_Float16));
+    unsigned long long t_tree = 0, t_net = 0, n_pass = 0;   // diagnostic (C4_TREE_STAMPS=1)
+    // A launch is a time quantum, not a number of rounds: every wave keeps alternating tree work and
+    // network passes until n_steps * time_budget cycles have passed, so all waves of the launch end
+    // together however many simulations their trees needed per network answer.
+    const unsigned long long t_launch = __builtin_amdgcn_s_memtime();
+    const unsigned long long quantum = (unsigned long long)n_steps * (unsigned long long)(d.time_budget > 0 ? d.time_budget : 80000);
+    while (__builtin_amdgcn_s_memtime() - t_launch < quantum) {
+        const unsigned long long ta = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));   // see c4_selfplay_kernel: keep the tree phase's addresses out of the net phase
+        const int lane = tid & (GROUP - 1);
+        const int grp = (tid & 63) / GROUP;
+        const int sl = (tid >> 6) + NWAVES * grp;     // slot of this 8-lane group inside the workgroup
+        if (grp < SPW)
+            tree_step<C4_EVAL_EXTERNAL_F32, false, true, true>(dw, slot0 + sl, lane, grp, s_path, s_l1, s_val, s_pri, nullptr, nullptr,
+                                                               &smem[sl], sl, s_stats);
+        lds_fence();   // the slot states written by the groups' first lanes are read by the whole wave
+        const unsigned long long tb = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
+        // the wave's own leaves, two per network pass
+        int pend_slot[SPW];
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < SPW; ++q) {
+            const int sq = wv + NWAVES * q;
+            const int has = __builtin_amdgcn_readfirstlane(smem[sq].has_leaf() ? 1 : 0);
+            if (has) pend_slot[cnt++] = sq;
+        }
+        for (int i = 0; i < cnt; i += WP) {
+            const int sa = pend_slot[i], sb = pend_slot[i + 1 < cnt ? i + 1 : i];
+            net_forward_wave_call(nd_dev, (lds_half *)&act[wv][0][0], (lds_half *)&act[wv][1][0], (const lds_float4 *)mlp,
+                                  smem[sa].leaf0, smem[sa].leaf1, smem[sb].leaf0, smem[sb].leaf1, min(WP, cnt - i),
+                                  (lds_float *)s_val, (lds_float *)s_pri, sa, sb);
+        }
+        lds_fence();   // answers (LDS) before the next tree_step reads them
+        if (d.has_stamps) { t_tree += tb - ta; t_net += __builtin_amdgcn_s_memtime() - tb; n_pass += (cnt + WP - 1) / WP; }
+    }
+    if (d.has_stamps && blockIdx.x < 128 && (threadIdx.x & 63) == 0) {   // per wave: tree cycles, net cycles | passes << 48
+        d.cold->stamps[blockIdx.x * 16 + wv] = t_tree;
+        d.cold->stamps[blockIdx.x * 16 + 8 + wv] = t_net | (n_pass << 48);
+    }
+    __syncthreads();
+    // ---- launch epilogue: LDS -> global
+    if (threadIdx.x < TS && slot0 + threadIdx.x < d.G) {
+        const int p = threadIdx.x, g = slot0 + p;
+        const SlotMem m = smem[p];
+        d.root_c0[g] = m.root0; d.root_c1[g] = m.root1; d.leaf_c0[g] = m.leaf0; d.leaf_c1[g] = m.leaf1;
+        d.game_id[g] = m.gid; d.sims_done[g] = m.sims; d.n_alloc[g] = m.nalloc; d.pending[g] = m.pend;
+        d.pending_depth[g] = m.pdepth; d.pending_info[g] = m.pinfo; d.need_root[g] = m.need_root();
+        d.ply[g] = m.ply; d.state[g] = m.state(); d.has_leaf[g] = m.has_leaf() ? 1 : 0;
+    }
+    if (threadIdx.x < N_STATS) d.stats[(size_t)slot0 * N_STATS + threadIdx.x] += s_stats[threadIdx.x];
+    for (int i = threadIdx.x; i < TS * 8; i += NTHREADS) {
+        const int p = i >> 3, k = i & 7;
+        if (slot0 + p < d.G) {
+            if (k == 7) values[slot0 + p] = s_val[p];
+            else priors[(size_t)(slot0 + p) * 7 + k] = s_pri[p * 7 + k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------
 __global__ void c4_reset_kernel(Dev d, const uint64_t *c0, const uint64_t *c1, int n_active)
@@ -1259,6 +1377,7 @@ struct c4_engine {
     std::vector<long long> drained_tag;   // per ring slot: game id already handed out (-1 none)
     int64_t launches;
     int fused_slots;      // slots per workgroup of the fused self-play kernel (16 or 32)
+    int fused_wave;       // 1: wave-autonomous fused kernel (c4_selfplay_wave_kernel)
     int tape_games;
     double *tape_noise, *tape_u;
     char err[512];
@@ -1373,6 +1492,8 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
         e->fused_slots = ((cfg->n_slots + 31) / 32 >= cus) ? 32 : 16;
+        e->fused_wave = 1;   // wave-autonomous kernel; C4_FUSED_MODE=block selects the workgroup-synchronous one
+        if (const char *fm = getenv("C4_FUSED_MODE")) e->fused_wave = strcmp(fm, "block") != 0;
         if (const char *fs = getenv("C4_FUSED_SLOTS")) {   // tuning aid: force 16 or 32
             const int v = atoi(fs);
             if (v == 16 || v == 32) e->fused_slots = v;
@@ -1589,7 +1710,12 @@ int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *prior
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
     // 32 slots per workgroup once that still gives every CU a workgroup (the tree phase is latency bound,
     // so its cost is shared by twice the slots); smaller batches keep 16 so that no CU stays idle
-    if (e->fused_slots == 32)
+    if (e->fused_wave) {   // wave-autonomous variant
+        if (e->fused_slots == 32)
+            hipLaunchKernelGGL(c4_selfplay_wave_kernel<32>, dim3((e->d.G + 31) / 32), dim3(c4net::NTHREADS), 0, st, e->d, nd, net->d_dev, values_dev, priors_dev, (int)n_steps);
+        else
+            hipLaunchKernelGGL(c4_selfplay_wave_kernel<16>, dim3((e->d.G + 15) / 16), dim3(c4net::NTHREADS), 0, st, e->d, nd, net->d_dev, values_dev, priors_dev, (int)n_steps);
+    } else if (e->fused_slots == 32)
         hipLaunchKernelGGL(c4_selfplay_kernel<32>, dim3((e->d.G + 31) / 32), dim3(c4net::NTHREADS), 0, st, e->d, nd, values_dev, priors_dev, (int)n_steps);
     else
         hipLaunchKernelGGL(c4_selfplay_kernel<16>, dim3((e->d.G + 15) / 16), dim3(c4net::NTHREADS), 0, st, e->d, nd, values_dev, priors_dev, (int)n_steps);

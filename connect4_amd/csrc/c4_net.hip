@@ -46,6 +46,25 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_kernel(NetDev nd, const uint6
     net_forward_block(nd, NetLds{lds, wbuf, mlp}, c0, c1, n, blockIdx.x * P, values, priors);
 }
 
+// Wave-private forward (net_forward_wave) as a kernel of its own: every wave evaluates two positions with
+// no workgroup barrier.  The fused self-play kernel uses the same device function; this entry point
+// exists so that it can be checked and timed in isolation.
+__global__ __launch_bounds__(NTHREADS) void c4_net_wave_kernel(NetDev nd, const uint64_t *__restrict__ c0,
+                                                               const uint64_t *__restrict__ c1, int n,
+                                                               float *__restrict__ values, float *__restrict__ priors)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 act[NWAVES][2][WACT];
+    __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
+    for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
+    __syncthreads();
+    const int wv = threadIdx.x >> 6;
+    const int pA = (blockIdx.x * NWAVES + wv) * WP, pB = pA + 1;
+    if (pA >= n) return;
+    const int npos = pB < n ? 2 : 1;
+    net_forward_wave(nd, &act[wv][0][0], &act[wv][1][0], mlp, c0[pA], c1[pA], npos == 2 ? c0[pB] : 0, npos == 2 ? c1[pB] : 0, npos,
+                     values, priors, pA, pB, (nd.stamps && blockIdx.x == 0) ? nd.stamps + wv * 16 : nullptr);
+}
+
 thread_local char n_err[512] = "";
 
 }  // namespace
@@ -93,6 +112,7 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
     c4_net *net = new c4_net();
     net->device = device;
     memset(&net->d, 0, sizeof(NetDev));
+    net->d_dev = nullptr;
     const int R = desc->n_residuals;
     // ---- stem: A[cout][k], k = tap*4 + ch (ch 3 zero), 48 = 3 k-steps; lane l holds cout l&31, k = 16s + 8(l>>5) + j
     std::vector<_Float16> stem(3 * 64 * 8), conv((size_t)2 * R * KSTEPS * 64 * 8), head(2 * 64 * 8);
@@ -174,6 +194,17 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
             net->d.stamps = (unsigned long long *)q;
         }
     }
+    {
+        void *q = nullptr;
+        if (hipMalloc(&q, sizeof(NetDev)) != hipSuccess || hipMemcpy(q, &net->d, sizeof(NetDev), hipMemcpyHostToDevice) != hipSuccess) {
+            snprintf(n_err, 512, "weight view upload failed");
+            if (q) (void)hipFree(q);
+            c4_net_destroy(net);
+            return C4_EDEVICE;
+        }
+        net->allocs.push_back(q);
+        net->d_dev = (NetDev *)q;
+    }
     *out = net;
     return C4_OK;
 }
@@ -201,6 +232,28 @@ int c4_net_forward(c4_net *net, void *hip_stream, const uint64_t *color0_dev, co
     hipError_t r = hipGetLastError();
     if (r != hipSuccess) {
         snprintf(n_err, 512, "c4_net_kernel launch failed: %s", hipGetErrorString(r));
+        return C4_EDEVICE;
+    }
+    return C4_OK;
+}
+
+/* Same contract as c4_net_forward, evaluated by the wave-private forward (two positions per wave, no
+ * workgroup barrier; bit-identical answers). */
+int c4_net_forward_wave(c4_net *net, void *hip_stream, const uint64_t *color0_dev, const uint64_t *color1_dev, int32_t n,
+                        float *values_dev, float *priors_dev)
+{
+    if (!net || !color0_dev || !color1_dev || !values_dev || !priors_dev || n < 0) {
+        snprintf(n_err, 512, "c4_net_forward_wave: bad argument");
+        return C4_EINVAL;
+    }
+    if (n == 0) return C4_OK;
+    const int per_block = NWAVES * WP;
+    const dim3 grid((n + per_block - 1) / per_block), block(NTHREADS);
+    hipLaunchKernelGGL(c4_net_wave_kernel, grid, block, 0, (hipStream_t)hip_stream, net->d, color0_dev, color1_dev, (int)n,
+                       values_dev, priors_dev);
+    hipError_t r = hipGetLastError();
+    if (r != hipSuccess) {
+        snprintf(n_err, 512, "c4_net_wave_kernel launch failed: %s", hipGetErrorString(r));
         return C4_EDEVICE;
     }
     return C4_OK;

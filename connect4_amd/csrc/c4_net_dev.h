@@ -401,11 +401,305 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
     stamp(11);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Wave-private forward: ONE wave evaluates up to WP = 2 positions (84 rows = 3 MFMA tiles) with no
+// workgroup barrier at all -- the fused self-play kernel lets every wave evaluate the leaves of its own
+// trees the moment they are needed instead of waiting for the slowest tree of the workgroup.
+//   * activations ping-pong between two private LDS buffers of (96 + 1 zero) rows x 40 halves;
+//   * the layer's 18 A fragments (weights) live in 72 VGPRs and come straight from global memory (the
+//     whole net is ~110 KB, L2 resident): fragment s of layer L+1 is requested into the same
+//     registers right after its last use in layer L, so the refill hides under a whole layer;
+//   * k-step outer, tile inner: three independent MFMAs back to back per k-step;
+//   * per-element arithmetic (bias as the accumulator's initial value, k order, identity-MFMA skip,
+//     epilogue, heads, MLPs) is the same as net_forward_block's, so both give bit-identical answers.
+// ------------------------------------------------------------------------------------------------
+constexpr int WP = 2;                        // positions per pass
+constexpr int WTILES = 3;
+constexpr int WROWS = WTILES * 32;           // 96 rows, 84 of them real for two positions
+constexpr int WACT = (WROWS + 1) * CS;       // halves per private activation buffer (7,760 B)
+
+// NT: tiles that hold real rows, 2 (one position) or 3 (two positions).  NL: number of conv layers when
+// it is known at compile time (the tower is then straight-line code, so the compiler's s_waitcnt
+// bookkeeping for the in-place weight refill is exact: in a runtime loop it falls back to vmcnt(0) in
+// front of every refill load and serialises them), 0 = runtime depth with unpipelined weight loads.
+template <int NT, int NL>
+__device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *a0, _Float16 *a1, const float4 *mlp,
+                                                    uint64_t bA0, uint64_t bA1, uint64_t bB0, uint64_t bB1, int npos,
+                                                    float *__restrict__ values, float *__restrict__ priors, int outA, int outB,
+                                                    unsigned long long *stamps = nullptr)
+{
+    const int lane = threadIdx.x & 63;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int nreal = npos * PIX;
+    auto stamp = [&](int i) { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); };   // diagnostic (C4_NET_STAMPS=1)
+    stamp(0);
+    const int n_layers = 2 * nd.n_res;
+    // this lane's 16 output channels are {8q + 4h + 0..3 : q = 0..3}
+    auto load_bias = [&](const float *b, float4 (&out)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[q] = *reinterpret_cast<const float4 *>(b + 8 * q + 4 * h);
+    };
+    // everything that comes from global memory is requested up front / a layer ahead
+    half8 w[KSTEPS];
+    if (NL > 0 && n_layers > 0) {
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) w[s] = nd.conv_w[s * 64 + lane];
+    }
+    half8 sw[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) sw[s] = nd.stem_w[s * 64 + lane];
+    float4 bias[4];
+    load_bias(nd.stem_b, bias);
+    // input planes (board.py:147-154), 4 halves per row, in a1 (the tower writes a1 only after the stem)
+    _Float16 *inp = a1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = lane + 64 * i;
+        if (r <= WROWS) {
+            half4 v = {};
+            if (r < nreal) {
+                const int p = r >= PIX ? 1 : 0, pix = r - p * PIX;
+                const int y = pix / 7, x = pix - y * 7;
+                const uint64_t b0 = p ? bB0 : bA0, b1 = p ? bB1 : bA1;
+                const int bit = x * 7 + (5 - y);
+                v[0] = (_Float16)((__popcll(b0 | b1) & 1) ? 0.0f : 1.0f);
+                v[1] = (_Float16)(float)((b0 >> bit) & 1);
+                v[2] = (_Float16)(float)((b1 >> bit) & 1);
+            }
+            *reinterpret_cast<half4 *>(inp + r * 4) = v;   // r == WROWS: the zero row of the planes
+        }
+    }
+    if (lane < CS) { a0[WROWS * CS + lane] = (_Float16)0.0f; a1[WROWS * CS + lane] = (_Float16)0.0f; }
+
+    // row geometry of the wave's tiles; rows that hold no real pixel read the zero row only
+    int rsel[NT][9], rbase[NT];
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        const int rg = ti * 32 + r32;
+        const int p = rg >= PIX ? 1 : 0, pix = rg - p * PIX;
+        const int y = pix / 7, x = pix - y * 7;
+        const bool real = rg < nreal;
+        rbase[ti] = rg * CS;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const int ok = -(int)(real && (unsigned)(y + dy) < 6u && (unsigned)(x + dx) < 7u);
+            rsel[ti][tap] = (((rg + dy * 7 + dx) & ok) | (WROWS & ~ok)) * CS + 8 * h;
+        }
+    }
+    // ------------------------------------------------------------------ stem: planes -> a0
+    {
+        floatx16 acc[NT];
+        half4 v[NT][6];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            const int rg = ti * 32 + r32;
+            const int p = rg >= PIX ? 1 : 0, pix = rg - p * PIX;
+            const int y = pix / 7, x = pix - y * 7;
+            const bool real = rg < nreal;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int tap = 4 * (i >> 1) + 2 * h + (i & 1);      // k = 16s + 8h + j = tap*4 + channel
+                const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;   // tap/3, tap%3 for tap < 12
+                const int ok = -(int)(real && tap < 9 && (unsigned)(y + ty - 1) < 6u && (unsigned)(x + tx - 1) < 7u);
+                const int row = ((rg + (ty - 1) * 7 + tx - 1) & ok) | (WROWS & ~ok);
+                v[ti][i] = *reinterpret_cast<const half4 *>(inp + row * 4);
+            }
+            acc[ti] = acc_from_bias(bias);
+        }
+        if (NL > 0 && n_layers > 0) load_bias(nd.conv_b, bias);   // first conv layer's bias: a stem ahead of its use
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) {
+                half8 bf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bf[j] = v[ti][2 * s][j]; bf[4 + j] = v[ti][2 * s + 1][j]; }
+                acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sw[s], bf, acc[ti], 0, 0, 0);
+            }
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) store_tile(acc[ti], a0, rbase[ti], h);
+    }
+    stamp(1);
+    half8 idf[2];   // identity A fragments: skip[cout][row] = sum_k I[cout][k] * x[k][row]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) idf[s][j] = (_Float16)((16 * s + 8 * h + j) == r32 ? 1.0f : 0.0f);
+    const half8 hw0 = nd.head_w[lane], hw1 = nd.head_w[64 + lane];
+    const float hb0 = nd.head_b[0], hb1 = nd.head_b[1], hb2 = nd.head_b[2];
+
+    // ------------------------------------------------------------------ residual tower
+    auto layer = [&](const int L, const bool pipelined) {
+        const _Float16 *src = (L & 1) ? a1 : a0;
+        _Float16 *dst = (L & 1) ? a0 : a1;
+        const bool second = L & 1;   // conv2 of a block: add the block input (lives in dst) and overwrite it
+        if (!pipelined) {            // runtime depth: this layer's weights and bias now
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) w[s] = nd.conv_w[((size_t)L * KSTEPS + s) * 64 + lane];
+            load_bias(nd.conv_b + L * F, bias);
+        }
+        floatx16 acc[NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) acc[ti] = acc_from_bias(bias);
+        // the refill is unconditional (the last layer re-requests layer 0): a branch around the loads
+        // makes the compiler drain vmcnt in front of each of them
+        const bool more = pipelined;
+        const int Ln = L + 1 < n_layers ? L + 1 : 0;
+        if (more) load_bias(nd.conv_b + Ln * F, bias);   // a layer ahead
+        const half8 *wnext = nd.conv_w + (size_t)Ln * WCHUNKS + lane;
+        half8 bfc[NT], bfn[NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) bfc[ti] = *reinterpret_cast<const half8 *>(src + rsel[ti][0]);
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            if (s + 1 < KSTEPS) {
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+                    bfn[ti] = *reinterpret_cast<const half8 *>(src + rsel[ti][(s + 1) >> 1] + ((s + 1) & 1) * 16);
+            }
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s], bfc[ti], acc[ti], 0, 0, 0);
+            if (more) w[s] = wnext[s * 64];   // fragment s of the next layer, a whole layer ahead of its use
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) bfc[ti] = bfn[ti];
+        }
+        if (second) {
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) {
+                const half8 x0 = *reinterpret_cast<const half8 *>(dst + rbase[ti] + 8 * h);
+                const half8 x1 = *reinterpret_cast<const half8 *>(dst + rbase[ti] + 16 + 8 * h);
+                acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[0], x0, acc[ti], 0, 0, 0);
+                acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[1], x1, acc[ti], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) store_tile(acc[ti], dst, rbase[ti], h);
+    };
+    if (NL > 0) {
+        for (int L = 0; L < n_layers; ++L) { layer(L, true); if (L < 6) stamp(2 + L); }
+    } else {
+        for (int L = 0; L < n_layers; ++L) layer(L, false);
+    }
+    // tower output is in a0 (n_layers is even)
+    stamp(8);
+
+    // ------------------------------------------------------------------ 1x1 head convs (value + 2 policy channels)
+    float *hs = reinterpret_cast<float *>(a1);   // [WP][HSTR] fp32: value plane 0..41, policy planes 42..125
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        const int rg = ti * 32 + r32;
+        const int p = rg >= PIX ? 1 : 0, pix = rg - p * PIX;
+        const half8 x0 = *reinterpret_cast<const half8 *>(a0 + rbase[ti] + 8 * h);
+        const half8 x1 = *reinterpret_cast<const half8 *>(a0 + rbase[ti] + 16 + 8 * h);
+        floatx16 acc = {};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hw0, x0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hw1, x1, acc, 0, 0, 0);
+        if (h == 0 && rg < WP * PIX) {   // couts 0..3 sit in registers 0..3 of the lower half-wave
+            hs[p * HSTR + 0 * PIX + pix] = lrelu(acc[0] + hb0);
+            hs[p * HSTR + 1 * PIX + pix] = lrelu(acc[1] + hb1);
+            hs[p * HSTR + 2 * PIX + pix] = lrelu(acc[2] + hb2);
+        }
+    }
+    if (lane < 2 * WP) hs[(lane >> 1) * HSTR + HEADV + (lane & 1)] = 0.0f;   // pad 126,127
+    stamp(9);
+    // ------------------------------------------------------------------ MLP heads (fp32 VALU), as in net_forward_block
+    {
+        const float *vt_b = reinterpret_cast<const float *>(mlp + VT_F4 + PT_F / 4);   // fc_b | vout_w | pfc_b
+        const float *pt = reinterpret_cast<const float *>(mlp + VT_F4);
+        const float4 *hA4 = reinterpret_cast<const float4 *>(hs);
+        const float4 *hB4 = reinterpret_cast<const float4 *>(hs + HSTR);
+        float v0 = 0.0f, v1 = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 11; ++g) {
+            const float4 wv = mlp[g * 64 + lane];
+            const float4 xa = hA4[g];
+            v0 += wv.x * xa.x + wv.y * xa.y + wv.z * xa.z + wv.w * xa.w;
+            if (NT == 3) {
+                const float4 xb = hB4[g];
+                v1 += wv.x * xb.x + wv.y * xb.y + wv.z * xb.z + wv.w * xb.w;
+            }
+        }
+        const int seg = lane >> 3;
+        const float *hpA = hs + PIX + seg * 11, *hpB = hs + HSTR + PIX + seg * 11;
+        float l0 = 0.0f, l1 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 11; ++c) {
+            const float wv = pt[c * 64 + lane];      // zero where seg*11 + c >= 84 or (lane & 7) == 7
+            const int cc = seg * 11 + c < 2 * PIX ? c : 2 * PIX - 1 - seg * 11;
+            l0 += wv * hpA[cc];
+            if (NT == 3) l1 += wv * hpB[cc];
+        }
+        l0 += dppf<0x128>(l0);
+        if (NT == 3) l1 += dppf<0x128>(l1);
+#pragma unroll
+        for (int m = 16; m <= 32; m <<= 1) {
+            l0 += __shfl_xor(l0, m, 64);
+            if (NT == 3) l1 += __shfl_xor(l1, m, 64);
+        }
+        const float fb = vt_b[lane], vw = vt_b[64 + lane], pb = vt_b[128 + lane];
+        const bool is_pol = lane < 7;
+#pragma unroll
+        for (int pp = 0; pp < (NT == 3 ? 2 : 1); ++pp) {
+            const float a = (pp ? v1 : v0) + fb;
+            const float lg = (pp ? l1 : l0) + pb;
+            const int go = pp ? outB : outA;
+            const float rs = sum16(lane < PIX ? vw * lrelu(a) : 0.0f);               // model.py:83-85
+            const float vsum = readlane_f(rs, 0) + readlane_f(rs, 16) + readlane_f(rs, 32);
+            const float value = (tanhf(vsum + nd.vout_b) + nd.w1) * nd.w2;           // model.py:86-88
+            const float mx = max8(is_pol ? lg : -INFINITY);
+            const float e = is_pol ? expf(lg - mx) : 0.0f;
+            const float sum = sum8(e);
+            if (pp < npos) {
+                if (lane == 0) values[go] = value;
+                if (is_pol) priors[(size_t)go * 7 + lane] = e / sum;
+            }
+        }
+    }
+    stamp(10);
+}
+
+__device__ __forceinline__ void net_forward_wave(const NetDev &nd, _Float16 *a0, _Float16 *a1, const float4 *mlp,
+                                                 uint64_t bA0, uint64_t bA1, uint64_t bB0, uint64_t bB1, int npos,
+                                                 float *__restrict__ values, float *__restrict__ priors, int outA, int outB,
+                                                 unsigned long long *stamps = nullptr)
+{
+    if (npos >= 2) net_forward_wave_nt<3, 1>(nd, a0, a1, mlp, bA0, bA1, bB0, bB1, 2, values, priors, outA, outB, stamps);
+    else net_forward_wave_nt<2, 1>(nd, a0, a1, mlp, bA0, bA1, bA0, bA1, 1, values, priors, outA, outA, stamps);
+}
+
+// Out-of-line entry for the fused self-play kernel: a real call gives the network its own register
+// allocation (220 VGPRs, no scratch) instead of sharing one with the tree walk it is inlined next to.
+// Pointers into LDS keep their address space across the call, so the body still uses ds_* instructions;
+// the weight view is read through a constant-address-space pointer (scalar loads).
+typedef __attribute__((address_space(3))) _Float16 lds_half;
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(3))) float4 lds_float4;
+typedef __attribute__((address_space(4))) const NetDev const_netdev;
+__device__ __attribute__((noinline)) void net_forward_wave_call(
+    const NetDev *ndp, lds_half *a0, lds_half *a1, const lds_float4 *mlp, uint64_t bA0, uint64_t bA1, uint64_t bB0, uint64_t bB1,
+    int npos, lds_float *values, lds_float *priors, int outA, int outB)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const_netdev *cp = (const_netdev *)ndp;   // constant address space: uniform scalar loads
+    NetDev nd;
+    nd.stem_w = cp->stem_w; nd.stem_b = cp->stem_b; nd.conv_w = cp->conv_w; nd.conv_b = cp->conv_b;
+    nd.head_w = cp->head_w; nd.head_b = cp->head_b; nd.mlp = cp->mlp;
+    nd.vout_b = cp->vout_b; nd.w1 = cp->w1; nd.w2 = cp->w2; nd.n_res = cp->n_res; nd.stamps = nullptr;
+#else
+    const NetDev nd = *ndp;
+#endif
+    net_forward_wave(nd, (_Float16 *)a0, (_Float16 *)a1, (const float4 *)mlp, bA0, bA1, bB0, bB1, npos, (float *)values,
+                     (float *)priors, outA, outB);
+}
+
 }  // namespace c4net
 
 // host-side handle behind c4_net_* (include/c4_engine.h)
 struct c4_net {
     int device;
     c4net::NetDev d;
+    c4net::NetDev *d_dev;   // device copy of `d` (read by the out-of-line network call of the fused kernel)
     std::vector<void *> allocs;
 };

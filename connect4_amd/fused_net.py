@@ -62,17 +62,19 @@ class FusedNet:
         if rc != L.OK:
             raise L.EngineError(rc, (self._lib.c4_net_last_error() or b"").decode())
 
-    def forward_bitboards(self, c0_ptr, c1_ptr, n, values, priors, stream=None):
-        """values/priors: torch float32 device tensors; c0_ptr/c1_ptr: device addresses of uint64[n]."""
+    def forward_bitboards(self, c0_ptr, c1_ptr, n, values, priors, stream=None, wave=False):
+        """values/priors: torch float32 device tensors; c0_ptr/c1_ptr: device addresses of uint64[n].
+        wave=True: the wave-private forward the fused self-play kernel uses (bit-identical answers)."""
         import torch
         if stream is None:
             stream = torch.cuda.current_stream(values.device).cuda_stream
-        rc = self._lib.c4_net_forward(self._h, C.c_void_p(stream), C.c_void_p(c0_ptr), C.c_void_p(c1_ptr), int(n),
-                                      C.c_void_p(values.data_ptr()), C.c_void_p(priors.data_ptr()))
+        fn = self._lib.c4_net_forward_wave if wave else self._lib.c4_net_forward
+        rc = fn(self._h, C.c_void_p(stream), C.c_void_p(c0_ptr), C.c_void_p(c1_ptr), int(n),
+                C.c_void_p(values.data_ptr()), C.c_void_p(priors.data_ptr()))
         if rc != L.OK:
             raise L.EngineError(rc, (self._lib.c4_net_last_error() or b"").decode())
 
-    def evaluate_bits(self, color0, color1):
+    def evaluate_bits(self, color0, color1, wave=False):
         """Convenience for tests: numpy uint64 arrays -> (values, priors) numpy."""
         import torch
         dev = torch.device("cuda", self.device)
@@ -81,7 +83,7 @@ class FusedNet:
         n = c0.numel()
         v = torch.zeros(n, dtype=torch.float32, device=dev)
         p = torch.zeros(n, 7, dtype=torch.float32, device=dev)
-        self.forward_bitboards(c0.data_ptr(), c1.data_ptr(), n, v, p)
+        self.forward_bitboards(c0.data_ptr(), c1.data_ptr(), n, v, p, wave=wave)
         torch.cuda.synchronize(dev)
         return v.cpu().numpy(), p.cpu().numpy()
 

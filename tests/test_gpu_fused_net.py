@@ -53,3 +53,20 @@ def test_fused_net_vs_pytorch_fp32(oracle, n):
     dv, dp = np.abs(v - rv.cpu().numpy()).max(), np.abs(p - rp.cpu().numpy()).max()
     print("n=%d fused vs torch fp32: max |dv| %.3g  max |dp| %.3g" % (n, dv, dp))
     assert dv < 2e-2 and dp < 2e-2
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 16, 33, 4099])
+def test_wave_private_forward_is_bit_identical(oracle, n):
+    """c4_net_forward_wave (one wave = two positions, no workgroup barrier: what the wave-autonomous
+    self-play kernel evaluates its leaves with) must answer exactly what c4_net_forward answers --
+    same per-element arithmetic in the same order -- for even, odd and ragged batch sizes, and with a
+    different tower depth (the runtime-depth path)."""
+    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.net import NetConfig, random_init_state_dict
+    for n_res in (3, 1):
+        sd = random_init_state_dict(NetConfig(n_residuals=n_res), seed=n_res)
+        net = FusedNet(sd)
+        c0, c1 = random_positions(oracle, n, seed=100 + n)
+        v, p = net.evaluate_bits(c0, c1)
+        wv, wp = net.evaluate_bits(c0, c1, wave=True)
+        assert np.array_equal(v, wv) and np.array_equal(p, wp)

@@ -14,6 +14,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--wave", type=int, default=0, help="1: the wave-private forward (two positions per wave)")
     args = ap.parse_args()
     from connect4_amd.fused_net import FusedNet
     from connect4_amd.net import InferenceNet, random_init_state_dict
@@ -27,13 +28,14 @@ def main():
     d1 = torch.from_numpy(c1.view(np.int64)).cuda()
     v = torch.zeros(args.n, device="cuda")
     p = torch.zeros(args.n, 7, device="cuda")
+    wave = bool(args.wave)
     for _ in range(10):
-        net.forward_bitboards(d0.data_ptr(), d1.data_ptr(), args.n, v, p)
+        net.forward_bitboards(d0.data_ptr(), d1.data_ptr(), args.n, v, p, wave=wave)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(args.iters):
-        net.forward_bitboards(d0.data_ptr(), d1.data_ptr(), args.n, v, p)
+        net.forward_bitboards(d0.data_ptr(), d1.data_ptr(), args.n, v, p, wave=wave)
     b.record()
     torch.cuda.synchronize()
     us = a.elapsed_time(b) * 1000 / args.iters
@@ -48,6 +50,12 @@ def main():
         out = (C.c_uint64 * 128)()
         rc = net._lib.c4_net_debug_stamps(net._h, out)
         st = np.array(list(out), dtype=np.int64).reshape(8, 16)
+        if wave:
+            names = ["start", "stem"] + ["L%d" % i for i in range(6)] + ["tower_end", "heads", "mlp"]
+            for w in range(8):
+                d = st[w, 1:11] - st[w, 0:10]
+                print("wave %d: " % w + " ".join("%s=%d" % (n, x) for n, x in zip(names[1:], d)) + "  total=%d" % (st[w, 10] - st[w, 0]))
+            return
         names = ["start", "stem", "bar0"] + ["L%d" % i for i in range(6)] + ["tower_end", "heads", "fc_end"]
         for w in range(8):
             d = st[w, 1:12] - st[w, 0:11]

@@ -84,10 +84,11 @@ def main():
                     help="fused: hand-written gfx950 MFMA kernel (fp16 storage, fp32 accumulate); torch: PyTorch-ROCm/MIOpen")
     ap.add_argument("--net-dtype", default=None, choices=["f32", "f16", "bf16"], help="torch net only (default f32)")
     ap.add_argument("--steps-per-graph", type=int, default=8)
-    ap.add_argument("--max-inner", type=int, default=32, help="evaluator-free simulations a slot may run per launch (0 = engine default)")
+    ap.add_argument("--max-inner", type=int, default=8, help="evaluator-free simulations a slot may run per tree call (0 = engine default)")
     ap.add_argument("--eval-cache", type=int, default=0, help="log2 entries of the evaluation cache (0 auto, -1 off)")
     ap.add_argument("--level-budget", type=int, default=0, help="descent levels per slot per launch (0 unlimited)")
-    ap.add_argument("--time-budget", type=int, default=80000, help="shader cycles per step call after which a slot starts no new simulation")
+    ap.add_argument("--time-budget", type=int, default=80000,
+                    help="shader cycles of one step: the fused kernel runs every wave for steps x this many cycles per launch")
     ap.add_argument("--pipeline", type=int, default=1, choices=[1, 2],
                     help="2: two half-batches on two streams, tree kernel of one half under the net of the other")
     ap.add_argument("--fused-loop", type=int, default=1, help="1: tree step + net in one persistent kernel")
@@ -159,10 +160,16 @@ def main():
     s0 = sp.stats()
     barrier()
     torch.cuda.synchronize()
+    # HIP events on the stream the kernels are launched on: the fused kernel's average launch duration
+    kstream = torch.cuda.current_stream()
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev_a.record(kstream)
     sp.run_steps(args.steps)
+    ev_b.record(kstream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    timed_gpu_ms = ev_a.elapsed_time(ev_b)
     barrier()
     s1 = sp.stats()
     delta = {k: s1[k] - s0[k] for k in s1}
@@ -273,6 +280,29 @@ def main():
                 pmc = json.load(f)
         except OSError:
             pass
+        fused = None
+        if args.fused_loop and args.net == "fused" and not args.pmc_mode:
+            # the timed region is back-to-back launches of ONE kernel; per launch of steps_per_launch steps:
+            n_launch = (args.steps + args.steps_per_launch - 1) // args.steps_per_launch
+            launch_ms = timed_gpu_ms / n_launch
+            r_sims, r_evals = delta["simulations"] / n_launch, (delta["leaf_evals"] - delta["eval_cache_hits"]) / n_launch
+            r_depth = delta["depth_sum"] / max(1, delta["simulations"])
+            tree_b = tree_bytes_per_sim(r_depth) * r_sims
+            ach = tree_b / (launch_ms * 1e-3) / 1e9
+            mfma_tf = NET_MFLOP_PER_POSITION * 1e6 * r_evals / (launch_ms * 1e-3) / 1e12
+            pmc_ok = args.slots == pmc.get("slots", 4096) and args.sims == 800 and args.max_inner == pmc.get("max_inner", -1) \
+                and args.steps_per_launch == pmc.get("steps_per_launch", 32) and pmc.get("kernel", "") == "c4_selfplay_wave_kernel"
+            fused = {
+                "kernel": "c4_selfplay_wave_kernel (per wave: PUCT tree walk of its slots + policy/value net on their leaves; the only kernel of the timed region)",
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                "traffic": ((pmc["FETCH_SIZE_fused"] + pmc["WRITE_SIZE_fused"]) * 1024.0 if pmc_ok and "FETCH_SIZE_fused" in pmc else None),
+                "avg_launch_ms": launch_ms, "launches": n_launch, "steps_per_launch": args.steps_per_launch,
+                "sims_per_launch": r_sims, "mean_depth": r_depth, "algorithmic_bytes_per_launch": tree_b,
+                "net_positions_per_launch": r_evals, "mfma_achieved_tflops": mfma_tf, "mfma_frac_of_dense_f16_peak": mfma_tf / BF16_MFMA_PEAK_TF,
+                "note": "tree walk = dependent-load (latency) bound pointer chase, bytes = (136*D+332) per simulation (node records, "
+                        "path, cache line); the network part of the same kernel is counted in mfma_achieved_tflops "
+                        "(4.74 MFLOP per evaluated leaf); duration = HIP events around the timed region / launches",
+            }
         if prof:
             ach = prof["tree_bytes_per_launch"] / (prof["tree_ms"] * 1e-3) / 1e9
             pmc_ok = args.slots == 4096 and args.sims == 800 and args.max_inner == pmc.get("max_inner", -1)
@@ -305,8 +335,11 @@ def main():
             }
             out["roofline_tree"] = tree
             out["roofline_net"] = netr
-            out["roofline"] = dict(tree if prof["tree_ms"] >= prof["net_ms"] else netr)   # the dominant kernel by time
-            out["roofline"]["share_of_step"] = max(prof["tree_ms"], prof["net_ms"]) / (prof["tree_ms"] + prof["net_ms"])
+            if fused is None:
+                out["roofline"] = dict(tree if prof["tree_ms"] >= prof["net_ms"] else netr)   # the dominant kernel by time
+                out["roofline"]["share_of_step"] = max(prof["tree_ms"], prof["net_ms"]) / (prof["tree_ms"] + prof["net_ms"])
+        if fused is not None:
+            out["roofline"] = fused   # the dominant (only) kernel of the timed region
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, args.sims, args.cpu_seconds, 256)
         print(json.dumps(out))

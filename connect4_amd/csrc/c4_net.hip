@@ -51,7 +51,8 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_kernel(NetDev nd, const uint6
 // exists so that it can be checked and timed in isolation.
 __global__ __launch_bounds__(NTHREADS) void c4_net_wave_kernel(NetDev nd, const uint64_t *__restrict__ c0,
                                                                const uint64_t *__restrict__ c1, int n,
-                                                               float *__restrict__ values, float *__restrict__ priors)
+                                                               float *__restrict__ values, float *__restrict__ priors,
+                                                               int active_waves, int pos_per_wave)
 {
     __shared__ __attribute__((aligned(16))) _Float16 act[NWAVES][2][WACT];
     __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_wave_kernel(NetDev nd, const 
     const int wv = threadIdx.x >> 6;
     const int pA = (blockIdx.x * NWAVES + wv) * WP, pB = pA + 1;
     if (pA >= n) return;
-    const int npos = pB < n ? 2 : 1;
+    if (wv >= active_waves) return;                       // diagnostic (C4_NET_WAVE_ACTIVE): fewer waves per CU
+    const int npos = (pB < n && pos_per_wave == 2) ? 2 : 1;   // diagnostic (C4_NET_WAVE_POS=1): one-position passes
     net_forward_wave(nd, &act[wv][0][0], &act[wv][1][0], mlp, c0[pA], c1[pA], npos == 2 ? c0[pB] : 0, npos == 2 ? c1[pB] : 0, npos,
                      values, priors, pA, pB, (nd.stamps && blockIdx.x == 0) ? nd.stamps + wv * 16 : nullptr);
 }
@@ -249,8 +251,9 @@ int c4_net_forward_wave(c4_net *net, void *hip_stream, const uint64_t *color0_de
     if (n == 0) return C4_OK;
     const int per_block = NWAVES * WP;
     const dim3 grid((n + per_block - 1) / per_block), block(NTHREADS);
+    const char *ea = getenv("C4_NET_WAVE_ACTIVE"), *ep = getenv("C4_NET_WAVE_POS");   // timing experiments only
     hipLaunchKernelGGL(c4_net_wave_kernel, grid, block, 0, (hipStream_t)hip_stream, net->d, color0_dev, color1_dev, (int)n,
-                       values_dev, priors_dev);
+                       values_dev, priors_dev, ea ? atoi(ea) : NWAVES, ep ? atoi(ep) : WP);
     hipError_t r = hipGetLastError();
     if (r != hipSuccess) {
         snprintf(n_err, 512, "c4_net_wave_kernel launch failed: %s", hipGetErrorString(r));

@@ -565,6 +565,7 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti) bfc[ti] = bfn[ti];
         }
+        if (L == 2) stamp(12);
         if (second) {
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti) {
@@ -574,8 +575,10 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
                 acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[1], x1, acc[ti], 0, 0, 0);
             }
         }
+        if (L == 2) stamp(13);
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) store_tile(acc[ti], dst, rbase[ti], h);
+        if (L == 2) stamp(14);
     };
     if (NL > 0) {
         for (int L = 0; L < n_layers; ++L) { layer(L, true); if (L < 6) stamp(2 + L); }

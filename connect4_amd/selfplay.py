@@ -25,7 +25,7 @@ class SelfPlay:
 
     def __init__(self, net: Callable, n_slots: int, config: MCTSConfig, seed: int = 0, device: int = 0,
                  games_target: int = -1, record_capacity_games: int = 0, planes_dtype=torch.float32,
-                 use_graph: bool = True, steps_per_graph: int = 8, max_inner_iters: int = 32,
+                 use_graph: bool = True, steps_per_graph: int = 8, max_inner_iters: int = 8,
                  eval_cache_log2_entries: int = 0, level_budget: int = 0, time_budget_cycles: int = 80000, pipeline: int = 1,
                  fused_loop: bool = False, steps_per_launch: int = 32):
         self.net = net

@@ -54,7 +54,8 @@ def main():
             names = ["start", "stem"] + ["L%d" % i for i in range(6)] + ["tower_end", "heads", "mlp"]
             for w in range(8):
                 d = st[w, 1:11] - st[w, 0:10]
-                print("wave %d: " % w + " ".join("%s=%d" % (n, x) for n, x in zip(names[1:], d)) + "  total=%d" % (st[w, 10] - st[w, 0]))
+                print("wave %d: " % w + " ".join("%s=%d" % (n, x) for n, x in zip(names[1:], d)) + "  total=%d" % (st[w, 10] - st[w, 0]) +
+                      "  | L2: k-loop=%d skip=%d epilogue=%d" % (st[w, 12] - st[w, 3], st[w, 13] - st[w, 12], st[w, 14] - st[w, 13]))
             return
         names = ["start", "stem", "bar0"] + ["L%d" % i for i in range(6)] + ["tower_end", "heads", "fc_end"]
         for w in range(8):

@@ -90,10 +90,11 @@ typedef struct {
     int32_t level_budget;              /* descent levels a slot may walk per launch; a descent that runs
                                           out is suspended and resumed by the next launch, so no launch
                                           waits for the deepest tree of the batch.  0 = unlimited */
-    int32_t time_budget_cycles;        /* a slot starts no further evaluator-free simulation once its step call
-                                          has run this many shader cycles (balances the waves of a launch by
-                                          cost instead of by count; which launch runs a simulation never
-                                          changes results).  0 = off */
+    int32_t time_budget_cycles;        /* c4_step / block-mode fused kernel: a slot starts no further evaluator-free
+                                          simulation once its step call has run this many shader cycles (balances
+                                          the waves of a launch by cost instead of by count).  Wave-autonomous
+                                          fused kernel: length of one step in shader cycles.  Which launch runs
+                                          a simulation never changes results.  0 = off / 80,000 */
     int32_t reserved[4];               /* must be 0 */
 } c4_config;
 
@@ -253,13 +254,19 @@ int c4_net_forward_wave(c4_net *net, void *hip_stream, const uint64_t *color0_de
                         int32_t n, float *values_dev, float *priors_dev);
 const char *c4_net_last_error(void);
 
-/* Fused persistent self-play: n_steps rounds of {c4_step for the workgroup's 32 slots; c4_net_forward
- * on the leaves they emitted, 16 per pass} in ONE launch -- no kernel boundary, no global barrier, a
- * workgroup waits only for its own trees; slot state, leaves and answers stay in LDS between the
- * rounds.  Same results as alternating c4_step / c4_net_forward.  values_dev float32 [n_slots],
- * priors_dev float32 [n_slots][7] are the hand-off buffers (must persist between calls).
- * Needs C4_EVAL_EXTERNAL_F32.  Per-slot rows of the statistics are only exact per workgroup after
- * this call (c4_get_stats sums them; the sums are exact). */
+/* Fused persistent self-play: the rollout step and the leaf evaluation of n_steps steps in ONE launch,
+ * no kernel boundary and no global barrier; slot state, leaves and answers stay in LDS for the whole
+ * launch.  Default (wave-autonomous kernel): every wave owns 2 slots (4 once n_slots gives every CU a
+ * 32-slot workgroup) and alternates the tree walk of its slots with the network on exactly their
+ * leaves -- no workgroup barrier either; a "step" is then a time quantum of
+ * c4_config.time_budget_cycles shader cycles (80,000 if 0) and the launch runs every wave for n_steps
+ * quanta, however many simulations its trees needed per network answer.  With the environment variable
+ * C4_FUSED_MODE=block: n_steps rounds of {tree step of the workgroup's 16/32 slots; barrier; network on
+ * the emitted leaves, 16 per pass; barrier}.  Either way the games are exactly those that alternating
+ * c4_step / c4_net_forward_wave launches play (which launch runs a simulation never changes a result).
+ * values_dev float32 [n_slots], priors_dev float32 [n_slots][7] are the hand-off buffers (must persist
+ * between calls).  Needs C4_EVAL_EXTERNAL_F32.  Per-slot rows of the statistics are only exact per
+ * workgroup after this call (c4_get_stats sums them; the sums are exact). */
 int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *priors_dev, int32_t n_steps,
                       void *hip_stream);
 /* diagnostic build aid: per-phase s_memtime stamps of workgroup 0, [8 waves][16]; needs the

@@ -419,11 +419,8 @@ constexpr int WTILES = 3;
 constexpr int WROWS = WTILES * 32;           // 96 rows, 84 of them real for two positions
 constexpr int WACT = (WROWS + 1) * CS;       // halves per private activation buffer (7,760 B)
 
-// NT: tiles that hold real rows, 2 (one position) or 3 (two positions).  NL: number of conv layers when
-// it is known at compile time (the tower is then straight-line code, so the compiler's s_waitcnt
-// bookkeeping for the in-place weight refill is exact: in a runtime loop it falls back to vmcnt(0) in
-// front of every refill load and serialises them), 0 = runtime depth with unpipelined weight loads.
-template <int NT, int NL>
+// NT: tiles that hold real rows, 2 (one position) or 3 (two positions).
+template <int NT>
 __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *a0, _Float16 *a1, const float4 *mlp,
                                                     uint64_t bA0, uint64_t bA1, uint64_t bB0, uint64_t bB1, int npos,
                                                     float *__restrict__ values, float *__restrict__ priors, int outA, int outB,
@@ -442,7 +439,7 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
     };
     // everything that comes from global memory is requested up front / a layer ahead
     half8 w[KSTEPS];
-    if (NL > 0 && n_layers > 0) {
+    if (n_layers > 0) {
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) w[s] = nd.conv_w[s * 64 + lane];
     }
@@ -508,7 +505,7 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
             }
             acc[ti] = acc_from_bias(bias);
         }
-        if (NL > 0 && n_layers > 0) load_bias(nd.conv_b, bias);   // first conv layer's bias: a stem ahead of its use
+        if (n_layers > 0) load_bias(nd.conv_b, bias);   // first conv layer's bias: a stem ahead of its use
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -531,23 +528,17 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
     const float hb0 = nd.head_b[0], hb1 = nd.head_b[1], hb2 = nd.head_b[2];
 
     // ------------------------------------------------------------------ residual tower
-    auto layer = [&](const int L, const bool pipelined) {
+    for (int L = 0; L < n_layers; ++L) {
         const _Float16 *src = (L & 1) ? a1 : a0;
         _Float16 *dst = (L & 1) ? a0 : a1;
         const bool second = L & 1;   // conv2 of a block: add the block input (lives in dst) and overwrite it
-        if (!pipelined) {            // runtime depth: this layer's weights and bias now
-#pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) w[s] = nd.conv_w[((size_t)L * KSTEPS + s) * 64 + lane];
-            load_bias(nd.conv_b + L * F, bias);
-        }
         floatx16 acc[NT];
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) acc[ti] = acc_from_bias(bias);
         // the refill is unconditional (the last layer re-requests layer 0): a branch around the loads
         // makes the compiler drain vmcnt in front of each of them
-        const bool more = pipelined;
         const int Ln = L + 1 < n_layers ? L + 1 : 0;
-        if (more) load_bias(nd.conv_b + Ln * F, bias);   // a layer ahead
+        load_bias(nd.conv_b + Ln * F, bias);   // a layer ahead
         const half8 *wnext = nd.conv_w + (size_t)Ln * WCHUNKS + lane;
         half8 bfc[NT], bfn[NT];
 #pragma unroll
@@ -561,7 +552,7 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
             }
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s], bfc[ti], acc[ti], 0, 0, 0);
-            if (more) w[s] = wnext[s * 64];   // fragment s of the next layer, a whole layer ahead of its use
+            w[s] = wnext[s * 64];   // fragment s of the next layer, a whole layer ahead of its use
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti) bfc[ti] = bfn[ti];
         }
@@ -579,11 +570,7 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) store_tile(acc[ti], dst, rbase[ti], h);
         if (L == 2) stamp(14);
-    };
-    if (NL > 0) {
-        for (int L = 0; L < n_layers; ++L) { layer(L, true); if (L < 6) stamp(2 + L); }
-    } else {
-        for (int L = 0; L < n_layers; ++L) layer(L, false);
+        if (L < 6) stamp(2 + L);
     }
     // tower output is in a0 (n_layers is even)
     stamp(8);
@@ -668,8 +655,8 @@ __device__ __forceinline__ void net_forward_wave(const NetDev &nd, _Float16 *a0,
                                                  float *__restrict__ values, float *__restrict__ priors, int outA, int outB,
                                                  unsigned long long *stamps = nullptr)
 {
-    if (npos >= 2) net_forward_wave_nt<3, 1>(nd, a0, a1, mlp, bA0, bA1, bB0, bB1, 2, values, priors, outA, outB, stamps);
-    else net_forward_wave_nt<2, 1>(nd, a0, a1, mlp, bA0, bA1, bA0, bA1, 1, values, priors, outA, outA, stamps);
+    if (npos >= 2) net_forward_wave_nt<3>(nd, a0, a1, mlp, bA0, bA1, bB0, bB1, 2, values, priors, outA, outB, stamps);
+    else net_forward_wave_nt<2>(nd, a0, a1, mlp, bA0, bA1, bA0, bA1, 1, values, priors, outA, outA, stamps);
 }
 
 // Out-of-line entry for the fused self-play kernel: a real call gives the network its own register

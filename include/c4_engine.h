@@ -77,9 +77,10 @@ typedef struct {
     int64_t games_target;              /* self-play: slots park once this many games were started;
                                           <0 = unbounded (bench) */
     int32_t record_capacity_games;     /* ring of finished-game records kept on device */
-    int32_t max_inner_iters;           /* cap on simulations a slot may complete inside one launch
-                                          without needing the evaluator (terminal leaves); bounds
-                                          launch time.  0 = default */
+    int32_t max_inner_iters;           /* cap on simulations a slot may complete inside one step call
+                                          without needing the evaluator (terminal or cached leaves);
+                                          bounds the duration of c4_step and of one tree call inside
+                                          the fused kernels.  0 = default */
     int32_t planes_dtype;              /* C4_PLANES_* layout of the leaf batch handed to the net */
     int32_t eval_cache_log2_entries;   /* device-wide evaluation cache = the reference's memo table
                                           (evaluators.py:9-25), shared by every slot and game: a leaf

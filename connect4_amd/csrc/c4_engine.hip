@@ -1140,9 +1140,8 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
 // bit-identical to net_forward_block's).
 // ------------------------------------------------------------------------------------------
 template <int TS>
-__global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(Dev d, c4net::NetDev nd, const c4net::NetDev *nd_dev,
-                                                                           float *__restrict__ values, float *__restrict__ priors,
-                                                                           int n_steps)
+__global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(Dev d, c4net::NetDev nd, float *__restrict__ values,
+                                                                           float *__restrict__ priors, int n_steps)
 {
     using namespace c4net;
     constexpr int SPW = TS / NWAVES;   // slots per wave
@@ -1153,6 +1152,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(Dev d
     __shared__ float s_val[TS];
     __shared__ float s_pri[TS * 7];
     __shared__ uint32_t s_stats[N_STATS];
+    __shared__ __attribute__((aligned(16))) float s_bias[BIAS_LDS_FLOATS];   // stem + conv biases (when the tower fits)
     static_assert((sizeof(PathEntry) * MAX_DEPTH + sizeof(Rec) * GROUP) * SPW <= sizeof(_Float16) * WACT, "a wave's path stacks must fit its activation buffer");
     const int slot0 = blockIdx.x * TS;
     const int wv = threadIdx.x >> 6;
@@ -1178,6 +1178,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(Dev d
         else s_pri[p * 7 + k] = ok ? priors[(size_t)(slot0 + p) * 7 + k] : 0.0f;
     }
     for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
+    stage_bias_lds(nd, s_bias);
     __syncthreads();
     Dev dw = d;
     dw.time_budget = 0;   // a call ends when a slot of the wave blocks; max_inner bounds it
@@ -1213,9 +1214,8 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(Dev d
         }
         for (int i = 0; i < cnt; i += WP) {
             const int sa = pend_slot[i], sb = pend_slot[i + 1 < cnt ? i + 1 : i];
-            net_forward_wave_call(nd_dev, (lds_half *)&act[wv][0][0], (lds_half *)&act[wv][1][0], (const lds_float4 *)mlp,
-                                  smem[sa].leaf0, smem[sa].leaf1, smem[sb].leaf0, smem[sb].leaf1, min(WP, cnt - i),
-                                  (lds_float *)s_val, (lds_float *)s_pri, sa, sb);
+            net_forward_wave(nd, &act[wv][0][0], &act[wv][1][0], mlp, s_bias, smem[sa].leaf0, smem[sa].leaf1, smem[sb].leaf0,
+                             smem[sb].leaf1, min(WP, cnt - i), s_val, s_pri, sa, sb);
         }
         lds_fence();   // answers (LDS) before the next tree_step reads them
         if (d.has_stamps) { t_tree += tb - ta; t_net += __builtin_amdgcn_s_memtime() - tb; n_pass += (cnt + WP - 1) / WP; }
@@ -1719,9 +1719,9 @@ int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *prior
     // so its cost is shared by twice the slots); smaller batches keep 16 so that no CU stays idle
     if (e->fused_wave) {   // wave-autonomous variant
         if (e->fused_slots == 32)
-            hipLaunchKernelGGL(c4_selfplay_wave_kernel<32>, dim3((e->d.G + 31) / 32), dim3(c4net::NTHREADS), 0, st, e->d, nd, net->d_dev, values_dev, priors_dev, (int)n_steps);
+            hipLaunchKernelGGL(c4_selfplay_wave_kernel<32>, dim3((e->d.G + 31) / 32), dim3(c4net::NTHREADS), 0, st, e->d, nd, values_dev, priors_dev, (int)n_steps);
         else
-            hipLaunchKernelGGL(c4_selfplay_wave_kernel<16>, dim3((e->d.G + 15) / 16), dim3(c4net::NTHREADS), 0, st, e->d, nd, net->d_dev, values_dev, priors_dev, (int)n_steps);
+            hipLaunchKernelGGL(c4_selfplay_wave_kernel<16>, dim3((e->d.G + 15) / 16), dim3(c4net::NTHREADS), 0, st, e->d, nd, values_dev, priors_dev, (int)n_steps);
     } else if (e->fused_slots == 32)
         hipLaunchKernelGGL(c4_selfplay_kernel<32>, dim3((e->d.G + 31) / 32), dim3(c4net::NTHREADS), 0, st, e->d, nd, values_dev, priors_dev, (int)n_steps);
     else

@@ -56,14 +56,16 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_wave_kernel(NetDev nd, const 
 {
     __shared__ __attribute__((aligned(16))) _Float16 act[NWAVES][2][WACT];
     __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
+    __shared__ __attribute__((aligned(16))) float s_bias[BIAS_LDS_FLOATS];
     for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
+    stage_bias_lds(nd, s_bias);
     __syncthreads();
     const int wv = threadIdx.x >> 6;
     const int pA = (blockIdx.x * NWAVES + wv) * WP, pB = pA + 1;
     if (pA >= n) return;
     if (wv >= active_waves) return;                       // diagnostic (C4_NET_WAVE_ACTIVE): fewer waves per CU
     const int npos = (pB < n && pos_per_wave == 2) ? 2 : 1;   // diagnostic (C4_NET_WAVE_POS=1): one-position passes
-    net_forward_wave(nd, &act[wv][0][0], &act[wv][1][0], mlp, c0[pA], c1[pA], npos == 2 ? c0[pB] : 0, npos == 2 ? c1[pB] : 0, npos,
+    net_forward_wave(nd, &act[wv][0][0], &act[wv][1][0], mlp, s_bias, c0[pA], c1[pA], npos == 2 ? c0[pB] : 0, npos == 2 ? c1[pB] : 0, npos,
                      values, priors, pA, pB, (nd.stamps && blockIdx.x == 0) ? nd.stamps + wv * 16 : nullptr);
 }
 
@@ -114,7 +116,6 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
     c4_net *net = new c4_net();
     net->device = device;
     memset(&net->d, 0, sizeof(NetDev));
-    net->d_dev = nullptr;
     const int R = desc->n_residuals;
     // ---- stem: A[cout][k], k = tap*4 + ch (ch 3 zero), 48 = 3 k-steps; lane l holds cout l&31, k = 16s + 8(l>>5) + j
     std::vector<_Float16> stem(3 * 64 * 8), conv((size_t)2 * R * KSTEPS * 64 * 8), head(2 * 64 * 8);
@@ -195,17 +196,6 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
             net->allocs.push_back(q);
             net->d.stamps = (unsigned long long *)q;
         }
-    }
-    {
-        void *q = nullptr;
-        if (hipMalloc(&q, sizeof(NetDev)) != hipSuccess || hipMemcpy(q, &net->d, sizeof(NetDev), hipMemcpyHostToDevice) != hipSuccess) {
-            snprintf(n_err, 512, "weight view upload failed");
-            if (q) (void)hipFree(q);
-            c4_net_destroy(net);
-            return C4_EDEVICE;
-        }
-        net->allocs.push_back(q);
-        net->d_dev = (NetDev *)q;
     }
     *out = net;
     return C4_OK;

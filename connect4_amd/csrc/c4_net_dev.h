@@ -115,6 +115,10 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
                                                   float *__restrict__ values, float *__restrict__ priors,
                                                   const int *out_map = nullptr)
 {
+    // laundered thread id (see net_forward_wave_nt): keeps this function's lane-derived addresses from being
+    // hoisted out of a persistent caller's step loop and spilled across its tree phase
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     // positions pos0 .. pos0+npos-1 are real; tiles that hold no real row are skipped in every stage
     // (a wave-uniform test), which is what a compacted, partly filled leaf batch pays for.
     // out_map (optional, P ints): output index of position p instead of pos0+p (compacted batches).
@@ -123,7 +127,7 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
     _Float16 (*lds)[(ROWS + 1) * CS] = L.act;
     half8 (*wbuf)[WCHUNKS] = L.wbuf;
     float4 *mlp = L.mlp;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = tid >> 6, lane = tid & 63;
     const int r32 = lane & 31, h = lane >> 5;
     const int n_layers = 2 * nd.n_res;
 
@@ -134,7 +138,7 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
             const half8 *wsrc = nd.conv_w + (size_t)L * WCHUNKS;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int c = threadIdx.x + i * NTHREADS;
+                const int c = tid + i * NTHREADS;
                 if (c < WCHUNKS) wpre[i] = wsrc[c];
             }
         }
@@ -143,7 +147,7 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
         if (L < n_layers) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int c = threadIdx.x + i * NTHREADS;
+                const int c = tid + i * NTHREADS;
                 if (c < WCHUNKS) wbuf[L & 1][c] = wpre[i];
             }
         }
@@ -161,7 +165,7 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
     // NN input planes (board.py:147-154) as 4 halves per (position,pixel) row: [to-move, o, x, 0];
     // they live in lds[1], which the tower only starts writing after the stem is done
     _Float16 *inp = lds[1];
-    for (int r = threadIdx.x; r <= ROWS; r += NTHREADS) {
+    for (int r = tid; r <= ROWS; r += NTHREADS) {
         half4 v = {};
         if (r < ROWS) {
             const int p = r / PIX, pix = r - p * PIX;
@@ -175,13 +179,13 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
         }
         *reinterpret_cast<half4 *>(inp + r * 4) = v;               // r == ROWS: the zero row of the planes
     }
-    if (threadIdx.x < CS) lds[0][ROWS * CS + threadIdx.x] = (_Float16)0.0f;                  // zero rows of the two
-    else if (threadIdx.x >= 64 && threadIdx.x < 64 + CS) lds[1][ROWS * CS + threadIdx.x - 64] = (_Float16)0.0f;   // activation buffers
+    if (tid < CS) lds[0][ROWS * CS + tid] = (_Float16)0.0f;                  // zero rows of the two
+    else if (tid >= 64 && tid < 64 + CS) lds[1][ROWS * CS + tid - 64] = (_Float16)0.0f;   // activation buffers
     {   // MLP tables: 928 float4, used only at the very end
-        const float4 m0 = nd.mlp[threadIdx.x];
-        const float4 m1 = threadIdx.x + NTHREADS < MLP_F4 ? nd.mlp[threadIdx.x + NTHREADS] : float4{0, 0, 0, 0};
-        mlp[threadIdx.x] = m0;
-        if (threadIdx.x + NTHREADS < MLP_F4) mlp[threadIdx.x + NTHREADS] = m1;
+        const float4 m0 = nd.mlp[tid];
+        const float4 m1 = tid + NTHREADS < MLP_F4 ? nd.mlp[tid + NTHREADS] : float4{0, 0, 0, 0};
+        mlp[tid] = m0;
+        if (tid + NTHREADS < MLP_F4) mlp[tid + NTHREADS] = m1;
     }
     __syncthreads();
 
@@ -332,7 +336,7 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
                 hs[p * HSTR + 2 * PIX + pix] = lrelu(acc[2] + hb2);
             }
         }
-        if (threadIdx.x < 2 * P) hs[(threadIdx.x >> 1) * HSTR + HEADV + (threadIdx.x & 1)] = 0.0f;   // pad 126,127
+        if (tid < 2 * P) hs[(tid >> 1) * HSTR + HEADV + (tid & 1)] = 0.0f;   // pad 126,127
     }
     __syncthreads();
     stamp(10);
@@ -422,11 +426,16 @@ constexpr int WACT = (WROWS + 1) * CS;       // halves per private activation bu
 // NT: tiles that hold real rows, 2 (one position) or 3 (two positions).
 template <int NT>
 __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *a0, _Float16 *a1, const float4 *mlp,
-                                                    uint64_t bA0, uint64_t bA1, uint64_t bB0, uint64_t bB1, int npos,
-                                                    float *__restrict__ values, float *__restrict__ priors, int outA, int outB,
-                                                    unsigned long long *stamps = nullptr)
+                                                    const float *bias_lds, uint64_t bA0, uint64_t bA1, uint64_t bB0, uint64_t bB1,
+                                                    int npos, float *__restrict__ values, float *__restrict__ priors, int outA,
+                                                    int outB, unsigned long long *stamps = nullptr)
 {
-    const int lane = threadIdx.x & 63;
+    // The lane id is laundered once per pass: inside a persistent kernel the compiler would otherwise hoist
+    // every lane-derived address of this function out of the caller's step loop, keep ~25 of them live
+    // across the tree walk and reload them from scratch (each reload drains vmcnt) in the middle of the pass.
+    int lane_ = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_));
+    const int lane = lane_;
     const int r32 = lane & 31, h = lane >> 5;
     const int nreal = npos * PIX;
     auto stamp = [&](int i) { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); };   // diagnostic (C4_NET_STAMPS=1)
@@ -446,8 +455,10 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
     half8 sw[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) sw[s] = nd.stem_w[s * 64 + lane];
+    // biases come from the caller's LDS copy (stem at 0, conv layer L at 32 * (1 + L)): four ds_read_b128
+    // at the start of a layer instead of 16 VGPRs of global prefetch held across the layer before
     float4 bias[4];
-    load_bias(nd.stem_b, bias);
+    load_bias(bias_lds, bias);
     // input planes (board.py:147-154), 4 halves per row, in a1 (the tower writes a1 only after the stem)
     _Float16 *inp = a1;
 #pragma unroll
@@ -470,7 +481,9 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
     if (lane < CS) { a0[WROWS * CS + lane] = (_Float16)0.0f; a1[WROWS * CS + lane] = (_Float16)0.0f; }
 
     // row geometry of the wave's tiles; rows that hold no real pixel read the zero row only
-    int rsel[NT][9], rbase[NT];
+    // tap offsets (in halves, < 2^16) packed two per register: taps 2j and 2j+1 share rsel2[ti][j]
+    uint32_t rsel2[NT][5];
+    int rbase[NT];
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) {
         const int rg = ti * 32 + r32;
@@ -479,12 +492,16 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
         const bool real = rg < nreal;
         rbase[ti] = rg * CS;
 #pragma unroll
+        for (int j = 0; j < 5; ++j) rsel2[ti][j] = 0;
+#pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
             const int ok = -(int)(real && (unsigned)(y + dy) < 6u && (unsigned)(x + dx) < 7u);
-            rsel[ti][tap] = (((rg + dy * 7 + dx) & ok) | (WROWS & ~ok)) * CS + 8 * h;
+            const uint32_t off = (uint32_t)((((rg + dy * 7 + dx) & ok) | (WROWS & ~ok)) * CS + 8 * h);
+            rsel2[ti][tap >> 1] |= off << (16 * (tap & 1));
         }
     }
+    auto rsel = [&](int ti, int tap) -> int { return (int)((rsel2[ti][tap >> 1] >> (16 * (tap & 1))) & 0xffffu); };
     // ------------------------------------------------------------------ stem: planes -> a0
     {
         floatx16 acc[NT];
@@ -505,7 +522,6 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
             }
             acc[ti] = acc_from_bias(bias);
         }
-        if (n_layers > 0) load_bias(nd.conv_b, bias);   // first conv layer's bias: a stem ahead of its use
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -519,13 +535,6 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
         for (int ti = 0; ti < NT; ++ti) store_tile(acc[ti], a0, rbase[ti], h);
     }
     stamp(1);
-    half8 idf[2];   // identity A fragments: skip[cout][row] = sum_k I[cout][k] * x[k][row]
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) idf[s][j] = (_Float16)((16 * s + 8 * h + j) == r32 ? 1.0f : 0.0f);
-    const half8 hw0 = nd.head_w[lane], hw1 = nd.head_w[64 + lane];
-    const float hb0 = nd.head_b[0], hb1 = nd.head_b[1], hb2 = nd.head_b[2];
 
     // ------------------------------------------------------------------ residual tower
     for (int L = 0; L < n_layers; ++L) {
@@ -533,22 +542,22 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
         _Float16 *dst = (L & 1) ? a0 : a1;
         const bool second = L & 1;   // conv2 of a block: add the block input (lives in dst) and overwrite it
         floatx16 acc[NT];
+        load_bias(bias_lds + F * (1 + L), bias);
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) acc[ti] = acc_from_bias(bias);
         // the refill is unconditional (the last layer re-requests layer 0): a branch around the loads
         // makes the compiler drain vmcnt in front of each of them
         const int Ln = L + 1 < n_layers ? L + 1 : 0;
-        load_bias(nd.conv_b + Ln * F, bias);   // a layer ahead
         const half8 *wnext = nd.conv_w + (size_t)Ln * WCHUNKS + lane;
         half8 bfc[NT], bfn[NT];
 #pragma unroll
-        for (int ti = 0; ti < NT; ++ti) bfc[ti] = *reinterpret_cast<const half8 *>(src + rsel[ti][0]);
+        for (int ti = 0; ti < NT; ++ti) bfc[ti] = *reinterpret_cast<const half8 *>(src + rsel(ti, 0));
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             if (s + 1 < KSTEPS) {
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
-                    bfn[ti] = *reinterpret_cast<const half8 *>(src + rsel[ti][(s + 1) >> 1] + ((s + 1) & 1) * 16);
+                    bfn[ti] = *reinterpret_cast<const half8 *>(src + rsel(ti, (s + 1) >> 1) + ((s + 1) & 1) * 16);
             }
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s], bfc[ti], acc[ti], 0, 0, 0);
@@ -558,6 +567,11 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
         }
         if (L == 2) stamp(12);
         if (second) {
+            half8 idf[2];   // identity A fragments: skip[cout][row] = sum_k I[cout][k] * x[k][row] (built where used)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) idf[s][j] = (_Float16)((16 * s + 8 * h + j) == r32 ? 1.0f : 0.0f);
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti) {
                 const half8 x0 = *reinterpret_cast<const half8 *>(dst + rbase[ti] + 8 * h);
@@ -577,6 +591,8 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
 
     // ------------------------------------------------------------------ 1x1 head convs (value + 2 policy channels)
     float *hs = reinterpret_cast<float *>(a1);   // [WP][HSTR] fp32: value plane 0..41, policy planes 42..125
+    const half8 hw0 = nd.head_w[lane], hw1 = nd.head_w[64 + lane];
+    const float hb0 = nd.head_b[0], hb1 = nd.head_b[1], hb2 = nd.head_b[2];
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) {
         const int rg = ti * 32 + r32;
@@ -650,38 +666,21 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
     stamp(10);
 }
 
-__device__ __forceinline__ void net_forward_wave(const NetDev &nd, _Float16 *a0, _Float16 *a1, const float4 *mlp,
-                                                 uint64_t bA0, uint64_t bA1, uint64_t bB0, uint64_t bB1, int npos,
-                                                 float *__restrict__ values, float *__restrict__ priors, int outA, int outB,
-                                                 unsigned long long *stamps = nullptr)
+constexpr int BIAS_LDS_LAYERS = 128;                        // c4_net_create accepts up to 64 residual blocks
+constexpr int BIAS_LDS_FLOATS = F * (1 + BIAS_LDS_LAYERS);  // 16.5 KB
+// cooperative fill of the LDS bias copy by the whole workgroup (the caller synchronises afterwards)
+__device__ __forceinline__ void stage_bias_lds(const NetDev &nd, float *bias_lds)
 {
-    if (npos >= 2) net_forward_wave_nt<3>(nd, a0, a1, mlp, bA0, bA1, bB0, bB1, 2, values, priors, outA, outB, stamps);
-    else net_forward_wave_nt<2>(nd, a0, a1, mlp, bA0, bA1, bA0, bA1, 1, values, priors, outA, outA, stamps);
+    const int n_layers = 2 * nd.n_res;
+    for (int i = threadIdx.x; i < F * (1 + n_layers); i += NTHREADS) bias_lds[i] = i < F ? nd.stem_b[i] : nd.conv_b[i - F];
 }
-
-// Out-of-line entry for the fused self-play kernel: a real call gives the network its own register
-// allocation (220 VGPRs, no scratch) instead of sharing one with the tree walk it is inlined next to.
-// Pointers into LDS keep their address space across the call, so the body still uses ds_* instructions;
-// the weight view is read through a constant-address-space pointer (scalar loads).
-typedef __attribute__((address_space(3))) _Float16 lds_half;
-typedef __attribute__((address_space(3))) float lds_float;
-typedef __attribute__((address_space(3))) float4 lds_float4;
-typedef __attribute__((address_space(4))) const NetDev const_netdev;
-__device__ __attribute__((noinline)) void net_forward_wave_call(
-    const NetDev *ndp, lds_half *a0, lds_half *a1, const lds_float4 *mlp, uint64_t bA0, uint64_t bA1, uint64_t bB0, uint64_t bB1,
-    int npos, lds_float *values, lds_float *priors, int outA, int outB)
+__device__ __forceinline__ void net_forward_wave(const NetDev &nd, _Float16 *a0, _Float16 *a1, const float4 *mlp,
+                                                 const float *bias_lds, uint64_t bA0, uint64_t bA1, uint64_t bB0, uint64_t bB1,
+                                                 int npos, float *__restrict__ values, float *__restrict__ priors, int outA,
+                                                 int outB, unsigned long long *stamps = nullptr)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const_netdev *cp = (const_netdev *)ndp;   // constant address space: uniform scalar loads
-    NetDev nd;
-    nd.stem_w = cp->stem_w; nd.stem_b = cp->stem_b; nd.conv_w = cp->conv_w; nd.conv_b = cp->conv_b;
-    nd.head_w = cp->head_w; nd.head_b = cp->head_b; nd.mlp = cp->mlp;
-    nd.vout_b = cp->vout_b; nd.w1 = cp->w1; nd.w2 = cp->w2; nd.n_res = cp->n_res; nd.stamps = nullptr;
-#else
-    const NetDev nd = *ndp;
-#endif
-    net_forward_wave(nd, (_Float16 *)a0, (_Float16 *)a1, (const float4 *)mlp, bA0, bA1, bB0, bB1, npos, (float *)values,
-                     (float *)priors, outA, outB);
+    if (npos >= 2) net_forward_wave_nt<3>(nd, a0, a1, mlp, bias_lds, bA0, bA1, bB0, bB1, 2, values, priors, outA, outB, stamps);
+    else net_forward_wave_nt<2>(nd, a0, a1, mlp, bias_lds, bA0, bA1, bA0, bA1, 1, values, priors, outA, outA, stamps);
 }
 
 }  // namespace c4net
@@ -690,6 +689,5 @@ __device__ __attribute__((noinline)) void net_forward_wave_call(
 struct c4_net {
     int device;
     c4net::NetDev d;
-    c4net::NetDev *d_dev;   // device copy of `d` (read by the out-of-line network call of the fused kernel)
     std::vector<void *> allocs;
 };

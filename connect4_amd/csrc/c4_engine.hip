@@ -387,7 +387,8 @@ __device__ __forceinline__ uint64_t group_xor64(uint64_t v)
     return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ uint64_t cache_key(uint64_t c0, uint64_t c1) { return c0 + (c0 | c1); }
-__device__ __forceinline__ CacheEntry *cache_slot(const Dev &d, uint64_t key)
+template <class DevT>
+__device__ __forceinline__ CacheEntry *cache_slot(DevT &d, uint64_t key)
 {
     return d.cache + ((key * 0x9E3779B97F4A7C15ULL) >> (64 - d.cache_bits));
 }
@@ -397,7 +398,8 @@ __device__ __forceinline__ uint64_t cache_check(uint64_t key, float value, float
     const uint32_t bits = lane < 7 ? __float_as_uint(prior_lane) : __float_as_uint(value);
     return key ^ group_xor64(mix64(((uint64_t)(lane + 1) << 32) | bits));
 }
-__device__ __forceinline__ bool cache_probe(const Dev &d, uint64_t c0, uint64_t c1, int lane, float &value, float &prior_lane)
+template <class DevT>
+__device__ __forceinline__ bool cache_probe(DevT &d, uint64_t c0, uint64_t c1, int lane, float &value, float &prior_lane)
 {
     const uint64_t key = cache_key(c0, c1);
     const CacheEntry *e = cache_slot(d, key);
@@ -406,7 +408,8 @@ __device__ __forceinline__ bool cache_probe(const Dev &d, uint64_t c0, uint64_t 
     prior_lane = lane < 7 ? e->prior[lane] : 0.0f;
     return k == key && chk == cache_check(key, value, prior_lane, lane);
 }
-__device__ __forceinline__ void cache_insert(const Dev &d, uint64_t c0, uint64_t c1, int lane, float value, float prior_lane)
+template <class DevT>
+__device__ __forceinline__ void cache_insert(DevT &d, uint64_t c0, uint64_t c1, int lane, float value, float prior_lane)
 {
     const uint64_t key = cache_key(c0, c1);
     CacheEntry *e = cache_slot(d, key);
@@ -432,8 +435,11 @@ template <> __device__ __forceinline__ void store_plane<hip_bfloat16>(void *p, s
 // and written to the Dev arrays and ai == g.
 // WAVE_SYNC (wave-autonomous fused kernel): the call ends as soon as any slot of this wave has left the
 // loop (it needs the evaluator, parked, ...), so the wave can evaluate that leaf right away.
-template <int EVAL, bool STAMPS = true, bool LDS_STATE = false, bool WAVE_SYNC = false>
-__device__ __forceinline__ void tree_step(const Dev &d, const int g, const int lane, const int gl,
+// DevT: `const Dev` (kernel argument, held in SGPRs) or a constant-address-space view of the engine's device
+// copy: the wave kernel reads each field with a scalar load where it is used instead of holding ~70
+// argument SGPRs (most of them spilled to VGPR lanes) for its whole lifetime.
+template <int EVAL, bool STAMPS = true, bool LDS_STATE = false, bool WAVE_SYNC = false, class DevT = const Dev>
+__device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, const int gl,
                                           PathEntry (*s_path)[MAX_DEPTH], Rec (*s_l1)[GROUP],
                                           const void *__restrict__ values_in,
                                           const void *__restrict__ priors_in, void *__restrict__ planes_out,
@@ -511,7 +517,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
     // time budget: a slot starts no further evaluator-free simulation once the call has run this many
     // shader cycles, so cheap (shallow / terminal / cached) simulations are not rationed by count and
     // every wave of a launch ends at about the same time
-    const unsigned long long t_begin = d.time_budget > 0 ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long t_begin = (!WAVE_SYNC && d.time_budget > 0) ? __builtin_amdgcn_s_memtime() : 0;
     bool resume = (pend == -2);
     // Hot subtree in LDS: once a launch has loaded the root's sibling block it stays in s_l1 for all
     // further simulations of the launch (write-through on every backup), so level 1 of every later
@@ -766,7 +772,7 @@ __device__ __forceinline__ void tree_step(const Dev &d, const int g, const int l
         // bound the launch: at most max_inner evaluator-free simulations per launch
         if (WAVE_SYNC && !resume && __builtin_amdgcn_ballot_w64(true) != wave_mask0) break;   // a neighbour needs the network
         if (!resume && (inner >= d.max_inner || levels_left <= 0 ||
-                        (d.time_budget > 0 && inner > 0 && (long long)(__builtin_amdgcn_s_memtime() - t_begin) > d.time_budget))) {
+                        (!WAVE_SYNC && d.time_budget > 0 && inner > 0 && (long long)(__builtin_amdgcn_s_memtime() - t_begin) > d.time_budget))) {
             st.capped += 1;
             break;
         }
@@ -1139,11 +1145,13 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
 // is there ~20 k cycles after the miss.  Same games as every other path (the network arithmetic is
 // bit-identical to net_forward_block's).
 // ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(4))) const Dev const_dev;
 template <int TS>
-__global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(Dev d, c4net::NetDev nd, float *__restrict__ values,
+__global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const Dev *d_dev, c4net::NetDev nd, float *__restrict__ values,
                                                                            float *__restrict__ priors, int n_steps)
 {
     using namespace c4net;
+    const_dev &d = *(const_dev *)d_dev;   // engine description: scalar loads from constant memory at the point of use
     constexpr int SPW = TS / NWAVES;   // slots per wave
     static_assert(TS % NWAVES == 0 && SPW >= 1 && SPW <= 8, "slots per workgroup");
     __shared__ __attribute__((aligned(16))) _Float16 act[NWAVES][2][WACT];   // private activation buffers of the waves
@@ -1180,8 +1188,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(Dev d
     for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
     stage_bias_lds(nd, s_bias);
     __syncthreads();
-    Dev dw = d;
-    dw.time_budget = 0;   // a call ends when a slot of the wave blocks; max_inner bounds it
+    // (a tree call ends when a slot of the wave blocks; max_inner bounds it)
     // the wave's path stacks and hot sibling blocks alias its first activation buffer (dead while the tree runs)
     PathEntry (*s_path)[MAX_DEPTH] = reinterpret_cast<PathEntry (*)[MAX_DEPTH]>(&act[wv][0][0]);
     Rec (*s_l1)[GROUP] = reinterpret_cast<Rec (*)[GROUP]>(&act[wv][0][0] + sizeof(PathEntry) * MAX_DEPTH * SPW / sizeof(_Float16));
@@ -1199,7 +1206,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(Dev d
         const int grp = (tid & 63) / GROUP;
         const int sl = (tid >> 6) + NWAVES * grp;     // slot of this 8-lane group inside the workgroup
         if (grp < SPW)
-            tree_step<C4_EVAL_EXTERNAL_F32, false, true, true>(dw, slot0 + sl, lane, grp, s_path, s_l1, s_val, s_pri, nullptr, nullptr,
+            tree_step<C4_EVAL_EXTERNAL_F32, false, true, true>(d, slot0 + sl, lane, grp, s_path, s_l1, s_val, s_pri, nullptr, nullptr,
                                                                &smem[sl], sl, s_stats);
         lds_fence();   // the slot states written by the groups' first lanes are read by the whole wave
         const unsigned long long tb = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
@@ -1373,6 +1380,8 @@ struct c4_engine {
     Dev d;
     Cold cold;        // host copy of *d.cold
     Cold *cold_dev;
+    Dev *d_dev;       // device copy of `d` (wave-autonomous kernel), refreshed when `d` changed
+    Dev d_uploaded;
     std::vector<void *> allocs;
     std::vector<long long> drained_tag;   // per ring slot: game id already handed out (-1 none)
     int64_t launches;
@@ -1506,6 +1515,8 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     memset(&e->d, 0, sizeof(Dev));
     memset(&e->cold, 0, sizeof(Cold));
     e->cold_dev = nullptr;
+    e->d_dev = nullptr;
+    memset(&e->d_uploaded, 0xff, sizeof(Dev));   // differs from any real description: the first launch uploads
     Dev &d = e->d;
     const size_t G = (size_t)cfg->n_slots;
     d.G = cfg->n_slots;
@@ -1591,6 +1602,7 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     }
     d.has_stamps = e->cold.stamps != nullptr;
     ALLOC(e->cold_dev, 1);
+    ALLOC(e->d_dev, 1);
 #undef ALLOC
     d.cold = e->cold_dev;
     if ((rc = sync_cold(e)) != C4_OK) { strncpy(g_err, e->err, 511); c4_engine_destroy(e); return rc; }
@@ -1717,11 +1729,16 @@ int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *prior
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
     // 32 slots per workgroup once that still gives every CU a workgroup (the tree phase is latency bound,
     // so its cost is shared by twice the slots); smaller batches keep 16 so that no CU stays idle
-    if (e->fused_wave) {   // wave-autonomous variant
+    if (e->fused_wave) {   // wave-autonomous variant; it reads the engine description from device memory
+        if (memcmp(&e->d_uploaded, &e->d, sizeof(Dev)) != 0) {
+            HIPCHK(e, hipMemcpyAsync(e->d_dev, &e->d, sizeof(Dev), hipMemcpyHostToDevice, st));
+            HIPCHK(e, hipStreamSynchronize(st));   // the source is a member that may change right after this call
+            e->d_uploaded = e->d;
+        }
         if (e->fused_slots == 32)
-            hipLaunchKernelGGL(c4_selfplay_wave_kernel<32>, dim3((e->d.G + 31) / 32), dim3(c4net::NTHREADS), 0, st, e->d, nd, values_dev, priors_dev, (int)n_steps);
+            hipLaunchKernelGGL(c4_selfplay_wave_kernel<32>, dim3((e->d.G + 31) / 32), dim3(c4net::NTHREADS), 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps);
         else
-            hipLaunchKernelGGL(c4_selfplay_wave_kernel<16>, dim3((e->d.G + 15) / 16), dim3(c4net::NTHREADS), 0, st, e->d, nd, values_dev, priors_dev, (int)n_steps);
+            hipLaunchKernelGGL(c4_selfplay_wave_kernel<16>, dim3((e->d.G + 15) / 16), dim3(c4net::NTHREADS), 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps);
     } else if (e->fused_slots == 32)
         hipLaunchKernelGGL(c4_selfplay_kernel<32>, dim3((e->d.G + 31) / 32), dim3(c4net::NTHREADS), 0, st, e->d, nd, values_dev, priors_dev, (int)n_steps);
     else

@@ -19,7 +19,7 @@ mi = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 net = FusedNet(random_init_state_dict(seed=0))
 sp = SelfPlay(net, slots, MCTSConfig.self_play(800), seed=0, use_graph=False, fused_loop=True, steps_per_launch=64,
               max_inner_iters=mi)
-sp.run_steps(6400)
+sp.run_steps(int(sys.argv[3]) if len(sys.argv) > 3 else 6400)
 sp.synchronize()
 s0 = sp.stats()
 sp.run_steps(64)

@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1, choices=[1, 2],
                     help="2: two half-batches on two streams, tree kernel of one half under the net of the other")
     ap.add_argument("--fused-loop", type=int, default=1, help="1: tree step + net in one persistent kernel")
-    ap.add_argument("--steps-per-launch", type=int, default=32)
+    ap.add_argument("--steps-per-launch", type=int, default=128)
     ap.add_argument("--pmc-mode", action="store_true",
                     help="for rocprofv3 --pmc passes: warm up with the fused kernel, then run the timed steps as "
                          "separate eager launches (no HIP graph: PMC collection crashes inside graph replay)")
@@ -291,7 +291,7 @@ def main():
             ach = tree_b / (launch_ms * 1e-3) / 1e9
             mfma_tf = NET_MFLOP_PER_POSITION * 1e6 * r_evals / (launch_ms * 1e-3) / 1e12
             pmc_ok = args.slots == pmc.get("slots", 4096) and args.sims == 800 and args.max_inner == pmc.get("max_inner", -1) \
-                and args.steps_per_launch == pmc.get("steps_per_launch", 32) and pmc.get("kernel", "") == "c4_selfplay_wave_kernel"
+                and args.steps_per_launch == pmc.get("steps_per_launch", 128) and pmc.get("kernel", "") == "c4_selfplay_wave_kernel"
             fused = {
                 "kernel": "c4_selfplay_wave_kernel (per wave: PUCT tree walk of its slots + policy/value net on their leaves; the only kernel of the timed region)",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,

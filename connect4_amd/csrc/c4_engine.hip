@@ -444,7 +444,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                                           const void *__restrict__ values_in,
                                           const void *__restrict__ priors_in, void *__restrict__ planes_out,
                                           uint64_t *leaf_out, SlotMem *sm = nullptr, const int ai_lds = 0,
-                                          uint32_t *wg_stats = nullptr)
+                                          uint32_t *wg_stats = nullptr, const unsigned long long deadline = 0)
 {
     if (leaf_out && lane < 2) leaf_out[lane] = 0;
     if (g >= d.slot_hi) return;
@@ -770,7 +770,9 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
         }
 
         // bound the launch: at most max_inner evaluator-free simulations per launch
-        if (WAVE_SYNC && !resume && __builtin_amdgcn_ballot_w64(true) != wave_mask0) break;   // a neighbour needs the network
+        // a neighbour needs the network, or the launch's time quantum is over
+        if (WAVE_SYNC && !resume && (__builtin_amdgcn_ballot_w64(true) != wave_mask0 ||
+                                     (long long)(__builtin_amdgcn_s_memtime() - deadline) > 0)) break;
         if (!resume && (inner >= d.max_inner || levels_left <= 0 ||
                         (!WAVE_SYNC && d.time_budget > 0 && inner > 0 && (long long)(__builtin_amdgcn_s_memtime() - t_begin) > d.time_budget))) {
             st.capped += 1;
@@ -1207,7 +1209,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
         const int sl = (tid >> 6) + NWAVES * grp;     // slot of this 8-lane group inside the workgroup
         if (grp < SPW)
             tree_step<C4_EVAL_EXTERNAL_F32, false, true, true>(d, slot0 + sl, lane, grp, s_path, s_l1, s_val, s_pri, nullptr, nullptr,
-                                                               &smem[sl], sl, s_stats);
+                                                               &smem[sl], sl, s_stats, t_launch + quantum);
         lds_fence();   // the slot states written by the groups' first lanes are read by the whole wave
         const unsigned long long tb = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
         // the wave's own leaves, two per network pass

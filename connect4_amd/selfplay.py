@@ -27,7 +27,7 @@ class SelfPlay:
                  games_target: int = -1, record_capacity_games: int = 0, planes_dtype=torch.float32,
                  use_graph: bool = True, steps_per_graph: int = 8, max_inner_iters: int = 8,
                  eval_cache_log2_entries: int = 0, level_budget: int = 0, time_budget_cycles: int = 80000, pipeline: int = 1,
-                 fused_loop: bool = False, steps_per_launch: int = 32):
+                 fused_loop: bool = False, steps_per_launch: int = 128):
         self.net = net
         self.n_slots = n_slots
         self.config = config

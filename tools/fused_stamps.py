@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: tree-phase vs net-phase cycles inside the fused self-play kernel (C4_TREE_STAMPS=1)."""
+"""Diagnostic: tree-phase vs net-phase cycles inside the workgroup-synchronous fused self-play kernel
+(C4_FUSED_MODE=block, C4_TREE_STAMPS=1).  For the default wave-autonomous kernel see wave_stamps.py."""
 import ctypes as C
 import os
 import sys
@@ -7,6 +8,7 @@ import sys
 import numpy as np
 
 os.environ["C4_TREE_STAMPS"] = "1"
+os.environ["C4_FUSED_MODE"] = "block"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from connect4_amd.config import MCTSConfig  # noqa: E402
 from connect4_amd.fused_net import FusedNet  # noqa: E402

@@ -1,19 +1,23 @@
 // c4_engine.hip -- MI355X (gfx950) self-play / MCTS engine behind the C ABI of include/c4_engine.h.
 //
 // Design (DESIGN.md has the long form):
-//   * thousands of games ("slots") advance in lock-step; each slot owns a private node pool in HBM
-//     laid out struct-of-arrays: N u32 | W f64 | P f64 | info u32, indexed slot*cap + node;
-//   * children of a node are created together in one 8-aligned block, in ascending column order, so
-//     the 7 lanes that score them read 7 consecutive elements of each array (one cache line each);
-//   * one slot = one 8-lane group of a wave64 (8 slots per wave): lane k scores child k, the PUCT
-//     argmax is a 3-step xor-shuffle butterfly over the group;
+//   * thousands of games ("slots") are searched side by side; each slot owns a private node pool in HBM
+//     of 32-byte records {W f64, Q f64, P f64, N u32, info u32};
+//   * the children of a node are created together as one 8-aligned 256-byte sibling block in ascending
+//     column order, so the 7 lanes that score them read it with two 16-byte loads each (two cache lines);
+//   * one slot = one 8-lane group of a wave64: lane k scores child k, the PUCT argmax is a 3-step DPP
+//     butterfly over the group (quad_perm x2 + row_half_mirror) that carries the winner's record along;
 //   * boards are never stored per node: the descent replays moves on a register bitboard;
 //   * children are materialised when their parent is EVALUATED (so the prior can live with the
 //     child); the reference's "expand on second visit" (mcts.py:114-115) is the moment a node with
 //     N==1 is first descended through -- that is what the expansion counter counts;
 //   * score arithmetic reproduces the reference bit-for-bit: float64 everywhere, or NumPy>=2's
 //     float32 path when the prior is a float32 net output (see ucb_score below); log() comes from a
-//     host-built table so device libm never enters the comparison.  Build with -ffp-contract=off.
+//     host-built table so device libm never enters the comparison.  Build with -ffp-contract=off;
+//   * three drivers share tree_step(): c4_step_kernel (one rollout step per launch, evaluator outside),
+//     c4_selfplay_kernel (workgroup-synchronous tree / network phases in one persistent kernel) and
+//     c4_selfplay_wave_kernel (the default: every wave alternates the tree walk of its own slots with
+//     the network on their leaves, no barrier; slot state lives in LDS for the whole launch).
 //
 // No CUDA-compat headers, no dual code paths, no CPU fallback: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>

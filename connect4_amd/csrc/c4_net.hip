@@ -15,11 +15,17 @@
 //     on the host into MFMA lane order); the next layer's 18 KiB are prefetched global -> registers
 //     -> LDS while the current layer computes, so no wave waits on L2 at a layer boundary;
 //   * activations ping-pong between two LDS buffers [672 rows][40 halves] (80-byte row stride makes
-//     the ds_read_b128 fragment reads bank-conflict free); zero padding is a per-row 9-bit tap
-//     mask, no halo; the residual add reads the skip element from the other buffer in the epilogue;
+//     the ds_read_b128 fragment reads bank-conflict free); zero padding = out-of-board taps read an
+//     all-zero row, no halo and no branch; the residual skip enters as two MFMAs against an identity
+//     matrix, the bias as the accumulator's initial value;
 //   * BatchNorm is folded into weights/bias on the host (eval mode), LeakyReLU(0.01) in the epilogue;
 //   * storage fp16, accumulation fp32 (same 10-bit mantissa as the TF32 path cuDNN uses by default
 //     for the reference's convs on its own GPU); heads and MLPs in fp32 on the VALU.
+//
+// Two forwards share this arithmetic (bit-identical answers): net_forward_block (above; c4_net_forward,
+// the workgroup-synchronous self-play kernel) and net_forward_wave (one wave = two positions, private
+// LDS buffers, weights streamed from L2 into registers, no workgroup barrier; c4_net_forward_wave and
+// the wave-autonomous self-play kernel).  Both live in c4_net_dev.h.
 #include <hip/hip_runtime.h>
 
 #include <cmath>

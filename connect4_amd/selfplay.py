@@ -1,5 +1,8 @@
-"""Device-resident self-play: the HIP rollout-step kernel and the leaf-batch network alternate on
-one HIP stream, captured as a HIP graph; no host round trip per simulation.
+"""Device-resident self-play; no host round trip per simulation.  With a FusedNet and fused_loop=True
+(what generate_games uses) the whole loop is ONE persistent kernel, c4_selfplay_steps: every wave
+alternates the tree walk of its own games with the policy/value network on their leaves.  Otherwise
+the HIP rollout-step kernel and the leaf-batch network (any device callable) alternate on one HIP
+stream, captured as a HIP graph.
 
 Stands in for TrainingLoop._generate_games' process/thread/pipe scaffolding
 (oinkoink/neural/training.py:99-135, game_pool.py:15-42, inference_server.py:37-63): every slot is

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libc4engine.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "c4_engine.h")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK, EINVAL, EDEVICE, ENOMEM, ESTATE, ECAPACITY = 0, -1, -2, -3, -4, -5
 RESULT_NONE, RESULT_XWIN, RESULT_DRAW, RESULT_OWIN = -1, 0, 1, 2
 EVAL_EXTERNAL_F32, EVAL_EXTERNAL_F64, EVAL_CENTRE = 0, 1, 2
@@ -40,7 +40,7 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "simulations", "expansions", "children_created", "terminal_sims", "leaf_evals", "depth_sum",
         "moves", "games_started", "games_finished", "launches", "active_slots", "capped_slots",
-        "eval_cache_hits", "eval_cache_probes", "bad_evals")]
+        "eval_cache_hits", "eval_cache_probes", "bad_evals", "dropped_games")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -61,15 +61,21 @@ class GameRecord(C.Structure):
                 ("value", C.c_double * 42), ("policy", (C.c_double * 7) * 42)]
 
 
+class ExportBuffers(C.Structure):
+    """c4_export_buffers: device pointers (torch.Tensor.data_ptr()) or None."""
+    _fields_ = [(n, C.c_void_p) for n in ("boards_dev", "moves_dev", "values_dev", "policy_dev", "targets_dev",
+                                          "game_index_dev", "lengths_dev", "results_dev", "ids_dev")]
+
+
 class NetDesc(C.Structure):
-    _fields_ = [("channels", C.c_int32), ("filters", C.c_int32), ("n_residuals", C.c_int32), ("reserved", C.c_int32)] + \
+    _fields_ = [("channels", C.c_int32), ("filters", C.c_int32), ("n_residuals", C.c_int32), ("precision", C.c_int32)] + \
         [(n, C.POINTER(C.c_float)) for n in ("stem_w", "stem_b", "conv_w", "conv_b", "head_w", "head_b",
                                              "vfc_w", "vfc_b", "vout_w", "pfc_w", "pfc_b")] + \
         [("vout_b", C.c_float), ("w1", C.c_float), ("w2", C.c_float), ("reserved2", C.c_float)]
 
 
 _P = C.POINTER
-_u64p, _i32p, _f32p, _f64p = _P(C.c_uint64), _P(C.c_int32), _P(C.c_float), _P(C.c_double)
+_u64p, _i32p, _f32p, _f64p, _i64p = _P(C.c_uint64), _P(C.c_int32), _P(C.c_float), _P(C.c_double), _P(C.c_int64)
 
 # name -> (restype, argtypes); every symbol include/c4_engine.h declares
 SIGNATURES = {
@@ -89,6 +95,13 @@ SIGNATURES = {
     "c4_get_stats": (C.c_int, [C.c_void_p, _P(Stats)]),
     "c4_read_roots": (C.c_int, [C.c_void_p, _P(RootResult)]),
     "c4_drain_games": (C.c_int, [C.c_void_p, _P(GameRecord), C.c_int32, _i32p]),
+    "c4_finished_games": (C.c_int, [C.c_void_p, _i64p, _i64p]),
+    "c4_export_games_dev": (C.c_int, [C.c_void_p, _P(ExportBuffers), C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "c4_training_tensors_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c4_eval_cache_lookup": (C.c_int, [C.c_void_p, _u64p, _u64p, C.c_int32, _f32p, _f32p, _i32p]),
+    "c4_debug_root_noise": (C.c_int, [C.c_int, C.c_uint64, C.c_double, _i64p, _i32p, _i32p, C.c_int32, _f64p, _f64p]),
+    "c4_debug_sample_move": (C.c_int, [C.c_int, C.c_uint64, _i64p, _i32p, _f64p, _i32p, _f64p, C.c_int32, _f64p, _i32p]),
     "c4_board_make_move": (C.c_int, [C.c_int, _u64p, _u64p, _i32p, C.c_int32, _u64p, _u64p, _i32p]),
     "c4_board_wins": (C.c_int, [C.c_int, _u64p, C.c_int32, _i32p]),
     "c4_board_valid_mask": (C.c_int, [C.c_int, _u64p, _u64p, C.c_int32, _i32p]),

@@ -145,14 +145,17 @@ struct Cold {
     const double *noise_tape;  // [tape_games][42][7]
     const double *u_tape;      // [tape_games][42]
     int tape_games;
-    // finished-game records, ring over game id
-    uint64_t *rec_c0, *rec_c1;   // [rec_cap][42]
-    int32_t *rec_move;
-    double *rec_value;
-    double *rec_policy;          // [rec_cap][42][7]
-    int32_t *game_len;           // [rec_cap] 0 = not finished
-    int32_t *game_result;
-    long long *game_tag;         // [rec_cap] id stored in the ring slot
+    // moves of the game in flight, per slot (training_game.py:12-15): [G][42] rows; copied to the ring
+    // of finished games when the game ends, so a slow game can never share a row with a newer one
+    uint64_t *stg_c0, *stg_c1;
+    int32_t *stg_move;
+    double *stg_value;
+    double *stg_policy;          // [G][42][7]
+    // finished games: ring of c4_game_record rows in completion order.  head = games recorded so far
+    // (device, CAS), tail = games consumed (drain / export); a game that finds the ring full is
+    // counted in `dropped` instead of overwriting an unread row.
+    c4_game_record *ring;        // [rec_cap]
+    unsigned long long *ring_head, *ring_tail, *dropped;
     unsigned long long *next_game;
     unsigned long long *stamps;   // diagnostic (C4_TREE_STAMPS=1): [block][8] s_memtime values, first 256 blocks
 };
@@ -375,6 +378,79 @@ __device__ __forceinline__ void group_pick(Pick &a)
     a.w = __longlong_as_double((long long)(((uint64_t)wh << 32) | wl));
 }
 
+// mcts.py:175-178: noise = Gamma(alpha, 1, size=7), zeroed on illegal columns and normalised (mcts.py:197-202)
+// with NumPy's sequential sum: a Dirichlet draw over the legal moves.  Lane k holds column k's raw draw.
+__device__ __forceinline__ double dirichlet_from_gamma(double nz, bool legal)
+{
+    if (!legal) nz = 0.0;
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) s = s + gshfl(nz, i);
+    return nz / s;
+}
+
+// tree.py:75-82 sample_value_fn(lambda x: x ** 2): weights V^2 over the root's children (lane k = child k,
+// `act` for k < nc), probabilities = weights / sum, then np.random.choice's inverse CDF for the uniform u:
+// cdf = cumsum(p); cdf /= cdf[-1]; index = searchsorted(cdf, u, side='right').  Returns -1 when every
+// weight is zero (the reference raises there).  V * V stands in for CPython's pow(V, 2.0): glibc's pow
+// differs from the correctly rounded square by one ulp for ~0.09 % of arguments, which can only move a
+// choice whose uniform lies within a few ulp of a CDF boundary (tests/test_gpu_rng.py bounds it).
+__device__ __forceinline__ int sample_child_sq(double V, bool act, uint32_t nc, double u, int lane)
+{
+    const double w2 = act ? V * V : 0.0;
+    double s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) s2 = s2 + gshfl(w2, i);
+    if (!(s2 > 0.0)) return -1;
+    const double pk = w2 / s2;
+    double acc = 0.0, cdf = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        acc = acc + gshfl(pk, i);
+        if (i == lane) cdf = acc;
+    }
+    const double last = gshfl(cdf, (int)nc - 1);
+    cdf = cdf / last;
+    const unsigned long long bal = __ballot(act && cdf <= u);
+    const int cnt = __popcll((bal >> (((threadIdx.x & 63) / GROUP) * GROUP)) & 0xffull);
+    return cnt < (int)nc ? cnt : (int)nc - 1;
+}
+
+// A finished game moves from its slot's staging rows into the ring of finished games (the reference's
+// games.extend(game_batch), training.py:131): one c4_game_record per game, in completion order.  A game
+// that finds the ring full (the host has not drained / exported for rec_cap games) is dropped and counted.
+template <class DevT>
+__device__ __forceinline__ void publish_game(DevT &d, int g, long long gid, int len, int32_t result, int lane)
+{
+    group_fence();   // this move's staging stores (lane 0 / lanes 0..6) are read back by other lanes below
+    int ok = 0;
+    unsigned long long t = 0;
+    if (lane == 0) {
+        const unsigned long long tail = *(volatile unsigned long long *)d.cold->ring_tail;
+        unsigned long long old = *(volatile unsigned long long *)d.cold->ring_head;
+        for (;;) {
+            if (old - tail >= (unsigned long long)d.rec_cap) { atomicAdd(d.cold->dropped, 1ULL); break; }
+            const unsigned long long seen = atomicCAS(d.cold->ring_head, old, old + 1);
+            if (seen == old) { ok = 1; t = old; break; }
+            old = seen;
+        }
+    }
+    ok = gshfl(ok, 0);
+    if (!ok) return;
+    t = ((unsigned long long)gshfl((uint32_t)(t >> 32), 0) << 32) | gshfl((uint32_t)t, 0);
+    c4_game_record *row = d.cold->ring + (size_t)(t % (unsigned long long)d.rec_cap);
+    const size_t s0 = (size_t)g * 42;
+    for (int i = lane; i < len; i += GROUP) {
+        row->color0[i] = d.cold->stg_c0[s0 + i];
+        row->color1[i] = d.cold->stg_c1[s0 + i];
+        row->move[i] = d.cold->stg_move[s0 + i];
+        row->value[i] = d.cold->stg_value[s0 + i];
+    }
+    double *rp = &row->policy[0][0];
+    for (int i = lane; i < len * 7; i += GROUP) rp[i] = d.cold->stg_policy[s0 * 7 + i];
+    if (lane == 0) { row->game_id = gid; row->length = len; row->result = result; }
+}
+
 // ---- evaluation cache ------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t x)
 {
@@ -577,11 +653,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                     if (d.rng_tape) nz = (gid < d.cold->tape_games) ? d.cold->noise_tape[((size_t)gid * 42 + ply) * 7 + lane] : 0.0;
                     else nz = rng_gamma(d.seed, gid, ply, (uint32_t)lane, d.alpha);
                 }
-                if (!legal) nz = 0.0;
-                double s = 0.0;
-#pragma unroll
-                for (int i = 0; i < 7; ++i) s = s + gshfl(nz, i);
-                nz = nz / s;
+                nz = dirichlet_from_gamma(nz, legal);
                 const double keep = 1.0 - d.frac;
                 const double a = SCORE_F32 ? (double)((float)prn * (float)keep) : prn * keep;
                 const double b = nz * d.frac;
@@ -688,26 +760,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                 if (d.rng_tape) u = (gid < d.cold->tape_games) ? d.cold->u_tape[(size_t)gid * 42 + ply] : -1.0;
                 else { double u1; rng_uniform2(d.seed, gid, ply, 32u, 0, u, u1); }
             }
-            if (u >= 0.0) {   // tree.py:75-82 sample_value_fn(x**2) via np.random.choice's inverse-CDF
-                const double w2 = V * V;
-                double s2 = 0.0;
-#pragma unroll
-                for (int i = 0; i < 7; ++i) s2 = s2 + gshfl(w2, i);
-                if (s2 > 0.0) {
-                    const double pk = w2 / s2;
-                    double acc = 0.0, cdf = 0.0;
-#pragma unroll
-                    for (int i = 0; i < 7; ++i) {
-                        acc = acc + gshfl(pk, i);
-                        if (i == lane) cdf = acc;
-                    }
-                    const double last = gshfl(cdf, (int)nc - 1);
-                    cdf = cdf / last;
-                    const unsigned long long bal = __ballot(act && cdf <= u);
-                    int cnt = __popcll((bal >> (((threadIdx.x & 63) / GROUP) * GROUP)) & 0xffull);
-                    kb = cnt < (int)nc ? cnt : (int)nc - 1;
-                }
-            }
+            if (u >= 0.0) kb = sample_child_sq(V, act, nc, u, lane);   // tree.py:75-82 sample_value_fn(x**2)
             if (kb < 0) kb = group_argmax(act ? V : -1.0, act ? lane : -1);   // tree.py:69-73 best_move
             const uint32_t bi = gshfl(ci, kb);
             const uint32_t bn = gshfl(cn, kb);
@@ -726,16 +779,16 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                 const double pv = gshfl(pol, kk & 7);
                 if (lane < 7 && ((rmask >> lane) & 1)) pol_col = pv;
             }
-            // training_game.py:12-15 record (board before the move)
+            // training_game.py:12-15 record (board before the move), staged per slot until the game ends
             if (d.rec_cap > 0 && !d.stop_after_move) {
-                const size_t r = ((size_t)(gid % d.rec_cap)) * 42 + ply;
+                const size_t r = (size_t)g * 42 + ply;
                 if (lane == 0) {
-                    d.cold->rec_c0[r] = root0;
-                    d.cold->rec_c1[r] = root1;
-                    d.cold->rec_move[r] = mv;
-                    d.cold->rec_value[r] = absv;
+                    d.cold->stg_c0[r] = root0;
+                    d.cold->stg_c1[r] = root1;
+                    d.cold->stg_move[r] = mv;
+                    d.cold->stg_value[r] = absv;
                 }
-                if (lane < 7) d.cold->rec_policy[r * 7 + lane] = pol_col;
+                if (lane < 7) d.cold->stg_policy[r * 7 + lane] = pol_col;
             }
             if (lane == 0) { d.cold->res_move[g] = mv; d.cold->res_value[g] = absv; }
             if (lane < 7) d.cold->res_policy[(size_t)g * 7 + lane] = pol_col;
@@ -747,13 +800,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             make_move(root0, root1, mv);   // board.make_move(child.name)
             ply += 1;
             if (bst >= ST_XWIN) {          // game over: training_game.py:17 game_data.result
-                if (d.rec_cap > 0 && lane == 0) {
-                    const size_t r = (size_t)(gid % d.rec_cap);
-                    d.cold->game_result[r] = (int32_t)(bst - ST_XWIN);
-                    d.cold->game_tag[r] = gid;
-                    __threadfence();
-                    d.cold->game_len[r] = (int32_t)ply;
-                }
+                if (d.rec_cap > 0) publish_game(d, g, gid, (int)ply, (int32_t)(bst - ST_XWIN), lane);
                 st.games_finished += 1;
                 unsigned long long ng = 0;
                 if (lane == 0) ng = atomicAdd(d.cold->next_game, 1ULL);
@@ -767,7 +814,6 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                 root0 = 0;
                 root1 = 0;
                 st.games_started += 1;
-                if (d.rec_cap > 0 && lane == 0) d.cold->game_len[(size_t)(gid % d.rec_cap)] = 0;
             }
             need_root = 1;
             continue;
@@ -1286,7 +1332,7 @@ __global__ void c4_reset_kernel(Dev d, const uint64_t *c0, const uint64_t *c1, i
     for (int i = 0; i < N_STATS; ++i) sp[i] = 0;
     if (active) sp[offsetof(SlotStats, games_started) / 8] = 1;
     if (g == 0) *d.cold->next_game = (unsigned long long)n_active;
-    for (int r = g; r < d.rec_cap; r += d.G) { d.cold->game_len[r] = 0; d.cold->game_result[r] = -1; d.cold->game_tag[r] = -1; }
+    if (g == 0) { *d.cold->ring_head = 0; *d.cold->ring_tail = 0; *d.cold->dropped = 0; }
 }
 
 __global__ void c4_gather_roots_kernel(Dev d, c4_root_result *out)
@@ -1366,6 +1412,153 @@ __global__ void k_centre(const uint64_t *c0, const uint64_t *c1, int n, double *
     if (i < n) out[i] = centre_value(c0[i], c1[i]);
 }
 
+__global__ void k_count_active(const int32_t *state, int G, int32_t *out)   // one block
+{
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    int c = 0;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) c += state[g] == SLOT_ACTIVE ? 1 : 0;
+    atomicAdd(&total, c);
+    __syncthreads();
+    if (threadIdx.x == 0) *out = total;
+}
+
+// ---- device-side export of finished games (no host round trip: head, tail and the counts stay on the device)
+// scratch: [0] games exported, [1] positions exported, [2] ring tail they start at, [4 + i] first position of game i
+constexpr int EXPORT_OFFS = 4;
+__global__ __launch_bounds__(1024) void k_export_scan(const Cold *cold, int rec_cap, int max_games, long long cap_pos, int64_t *scratch)
+{
+    __shared__ long long part[1024];
+    __shared__ long long base;
+    __shared__ int n_ok;
+    const int tid = threadIdx.x;
+    const unsigned long long head = *cold->ring_head, tail = *cold->ring_tail;
+    long long avail = (long long)(head - tail);
+    if (avail > max_games) avail = max_games;
+    if (tid == 0) { base = 0; n_ok = 0; }
+    __syncthreads();
+    for (long long chunk = 0; chunk < avail; chunk += 1024) {
+        const long long i = chunk + tid;
+        const long long len = i < avail ? cold->ring[(tail + (unsigned long long)i) % (unsigned long long)rec_cap].length : 0;
+        part[tid] = len;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {   // inclusive scan of the chunk
+            const long long v = tid >= o ? part[tid - o] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        const long long incl = base + part[tid];
+        if (i < avail) {
+            scratch[EXPORT_OFFS + i] = incl - len;
+            if (incl <= cap_pos) atomicMax(&n_ok, (int)(i + 1));   // lengths >= 1: the games that fit are a prefix
+        }
+        __syncthreads();
+        if (tid == 0) base += part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int n = n_ok;
+        scratch[0] = n;
+        scratch[1] = n ? scratch[EXPORT_OFFS + n - 1] + cold->ring[(tail + (unsigned long long)(n - 1)) % (unsigned long long)rec_cap].length : 0;
+        scratch[2] = (int64_t)tail;
+    }
+}
+__global__ __launch_bounds__(64) void k_export_write(const Cold *cold, int rec_cap, const int64_t *scratch, c4_export_buffers b)
+{
+    const long long n = scratch[0];
+    const unsigned long long tail = (unsigned long long)scratch[2];
+    const int t = threadIdx.x;
+    for (long long i = blockIdx.x; i < n; i += gridDim.x) {
+        const c4_game_record *row = cold->ring + (size_t)((tail + (unsigned long long)i) % (unsigned long long)rec_cap);
+        const int len = row->length;
+        const long long p = scratch[EXPORT_OFFS + i] + t;
+        if (t < len) {
+            if (b.boards_dev) { b.boards_dev[2 * p] = (int64_t)row->color0[t]; b.boards_dev[2 * p + 1] = (int64_t)row->color1[t]; }
+            if (b.moves_dev) b.moves_dev[p] = (uint8_t)row->move[t];
+            if (b.values_dev) b.values_dev[p] = (float)row->value[t];
+            if (b.targets_dev) b.targets_dev[p] = 0.5f * (float)row->result;        // training_game.py:57-60
+            if (b.policy_dev)
+                for (int k = 0; k < 7; ++k) b.policy_dev[p * 7 + k] = (float)row->policy[t][k];
+            if (b.game_index_dev) b.game_index_dev[p] = (int32_t)i;
+        }
+        if (t == 0) {
+            if (b.lengths_dev) b.lengths_dev[i] = len;
+            if (b.results_dev) b.results_dev[i] = (int8_t)row->result;
+            if (b.ids_dev) b.ids_dev[i] = row->game_id;
+        }
+    }
+}
+__global__ void k_export_commit(const Cold *cold, const int64_t *scratch, int64_t *counts_out)
+{
+    *cold->ring_tail = (unsigned long long)(scratch[2] + scratch[0]);
+    if (counts_out) { counts_out[0] = scratch[0]; counts_out[1] = scratch[1]; }
+}
+
+// data.py:78-105 native_to_pytorch(add_fliplr=True) on device: originals, then the mirrored copies
+// (boards mirrored by column board.py:115-145, priors reversed, values duplicated)
+__global__ void k_training_tensors(const int64_t *boards, const float *targets, const float *policy, long long n, int flip,
+                                   float *ob, float *ov, float *op)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = n * (flip ? 2 : 1);
+    if (t >= total * 126) return;
+    const long long j = t / 126;
+    const int e = (int)(t - j * 126);
+    const bool mirrored = j >= n;
+    const long long src = mirrored ? j - n : j;
+    uint64_t c0 = (uint64_t)boards[2 * src], c1 = (uint64_t)boards[2 * src + 1];
+    if (mirrored) { c0 = flip_color(c0); c1 = flip_color(c1); }
+    const int o_to_move = (popc64(c0 | c1) & 1) ? 0 : 1;
+    ob[t] = plane_element(c0, c1, o_to_move, e);
+    if (e < 7) op[j * 7 + e] = policy[src * 7 + (mirrored ? 6 - e : e)];
+    if (e == 7) ov[j] = targets[src];
+}
+
+// evaluation-cache read-out: what the cache answers for given positions (8 lanes per position, like the walk)
+__global__ __launch_bounds__(64) void k_cache_lookup(Dev d, const uint64_t *c0, const uint64_t *c1, int n, float *value, float *prior,
+                                                     int32_t *found)
+{
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int idx = (blockIdx.x * 64 + threadIdx.x) / GROUP;
+    const int i = idx < n ? idx : n - 1;   // every lane takes part in the group reductions
+    float v, pl;
+    const bool hit = cache_probe(d, c0[i], c1[i], lane, v, pl);
+    if (idx < n) {
+        if (lane < 7) prior[(size_t)i * 7 + lane] = hit ? pl : 0.0f;
+        if (lane == 0) { value[i] = hit ? v : 0.0f; found[i] = hit ? 1 : 0; }
+    }
+}
+
+// production RNG read-outs: exactly the device functions the move choice / root noise use
+__global__ __launch_bounds__(64) void k_debug_noise(uint64_t seed, double alpha, const long long *gid, const int32_t *ply,
+                                                    const int32_t *legal_mask, int n, double *raw, double *dirichlet)
+{
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int idx = (blockIdx.x * 64 + threadIdx.x) / GROUP;
+    const int i = idx < n ? idx : n - 1;
+    const bool legal = lane < 7 && ((legal_mask[i] >> lane) & 1);
+    const double g = lane < 7 ? rng_gamma(seed, gid[i], (uint32_t)ply[i], (uint32_t)lane, alpha) : 0.0;
+    const double nz = dirichlet_from_gamma(g, legal);
+    if (idx < n && lane < 7) { raw[(size_t)i * 7 + lane] = g; dirichlet[(size_t)i * 7 + lane] = nz; }
+}
+__global__ __launch_bounds__(64) void k_debug_sample(uint64_t seed, const long long *gid, const int32_t *ply, const double *child_values,
+                                                     const int32_t *n_children, const double *u_in, int n, double *u_out, int32_t *choice)
+{
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int idx = (blockIdx.x * 64 + threadIdx.x) / GROUP;
+    const int i = idx < n ? idx : n - 1;
+    const uint32_t nc = (uint32_t)n_children[i];
+    const bool act = lane < (int)nc;
+    const double V = act ? child_values[(size_t)i * 7 + lane] : 0.0;
+    double u, u1;
+    if (u_in) u = u_in[i];
+    else rng_uniform2(seed, gid[i], (uint32_t)ply[i], 32u, 0, u, u1);
+    const int kb = sample_child_sq(V, act, nc, u, lane);
+    if (idx < n && lane == 0) { u_out[i] = u; choice[i] = kb; }
+}
+
 thread_local char g_err[512] = "";
 
 void set_err(char *dst, const char *fmt, ...)
@@ -1389,7 +1582,8 @@ struct c4_engine {
     Dev *d_dev;       // device copy of `d` (wave-autonomous kernel), refreshed when `d` changed
     Dev d_uploaded;
     std::vector<void *> allocs;
-    std::vector<long long> drained_tag;   // per ring slot: game id already handed out (-1 none)
+    int32_t *active_dev;                  // scratch: live-slot count (c4_run_centre)
+    int64_t *export_scratch;              // device: [0] games, [1] positions of the last export, [2..] per-game offsets
     int64_t launches;
     int fused_slots;      // slots per workgroup of the fused self-play kernel (16 or 32)
     int fused_wave;       // 1: wave-autonomous fused kernel (c4_selfplay_wave_kernel)
@@ -1479,7 +1673,7 @@ int c4_abi_version(void) { return C4_ABI_VERSION; }
 int c4_debug_stamps(c4_engine *e, unsigned long long *out)
 {
     if (!e || !out || !e->cold.stamps) return C4_ESTATE;
-    if (hipStreamSynchronize(e->stream) != hipSuccess) return C4_EDEVICE;
+    if (hipDeviceSynchronize() != hipSuccess) return C4_EDEVICE;
     return hipMemcpy(out, e->cold.stamps, 256 * 8 * 8, hipMemcpyDeviceToHost) == hipSuccess ? C4_OK : C4_EDEVICE;
 }
 
@@ -1562,9 +1756,13 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     ALLOC(e->cold.res_move, G); ALLOC(e->cold.res_value, G); ALLOC(e->cold.res_policy, G * 7);
     ALLOC(e->cold.next_game, 1);
     const size_t R = (size_t)d.rec_cap;
-    ALLOC(e->cold.rec_c0, R * 42); ALLOC(e->cold.rec_c1, R * 42); ALLOC(e->cold.rec_move, R * 42);
-    ALLOC(e->cold.rec_value, R * 42); ALLOC(e->cold.rec_policy, R * 42 * 7);
-    ALLOC(e->cold.game_len, R); ALLOC(e->cold.game_result, R); ALLOC(e->cold.game_tag, R);
+    const size_t SG = R ? G : 0;   // staging rows only when games are recorded
+    ALLOC(e->cold.stg_c0, SG * 42); ALLOC(e->cold.stg_c1, SG * 42); ALLOC(e->cold.stg_move, SG * 42);
+    ALLOC(e->cold.stg_value, SG * 42); ALLOC(e->cold.stg_policy, SG * 42 * 7);
+    ALLOC(e->cold.ring, R);
+    ALLOC(e->cold.ring_head, 1); ALLOC(e->cold.ring_tail, 1); ALLOC(e->cold.dropped, 1);
+    ALLOC(e->active_dev, 1);
+    ALLOC(e->export_scratch, R + 4);
     // score tables (host libm so that log() is the very function Python's math.log calls)
     {
         const size_t nt = (size_t)cfg->simulations + 4;
@@ -1578,7 +1776,6 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
         if (hipMemcpy(tAB, AB.data(), nt * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess) { set_err(g_err, "table upload failed"); c4_engine_destroy(e); return C4_EDEVICE; }
         d.tabAB = tAB;
     }
-    e->drained_tag.assign(R, -1);
     {   // evaluation cache: <0 off, 0 auto (self-play with a float32 evaluator only), else log2(entries)
         int bits = cfg->eval_cache_log2_entries;
         if (bits == 0 && cfg->eval_mode == C4_EVAL_EXTERNAL_F32 && !cfg->stop_after_move) {
@@ -1635,7 +1832,7 @@ int c4_clear_eval_cache(c4_engine *e)
     if (!e) return C4_EINVAL;
     if (!e->d.cache) return C4_OK;
     HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipDeviceSynchronize());
     HIPCHK(e, hipMemset(e->d.cache, 0xFF, sizeof(CacheEntry) << e->d.cache_bits));
     return C4_OK;
 }
@@ -1653,6 +1850,7 @@ int c4_reset(c4_engine *e, const uint64_t *color0, const uint64_t *color1, int32
     if (n_active < 0 || n_active > e->d.G) { set_err(e->err, "n_active=%d out of range [0,%d]", n_active, e->d.G); return C4_EINVAL; }
     if ((color0 == nullptr) != (color1 == nullptr)) { set_err(e->err, "color0/color1 must both be given or both NULL"); return C4_EINVAL; }
     HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipDeviceSynchronize());
     uint64_t *d0 = nullptr, *d1 = nullptr;
     if (color0) {
         for (int i = 0; i < n_active; ++i)
@@ -1672,7 +1870,6 @@ int c4_reset(c4_engine *e, const uint64_t *color0, const uint64_t *color1, int32
     HIPCHK(e, hipStreamSynchronize(e->stream));
     if (d0) (void)hipFree(d0);
     if (d1) (void)hipFree(d1);
-    std::fill(e->drained_tag.begin(), e->drained_tag.end(), -1LL);
     e->launches = 0;
     return C4_OK;
 }
@@ -1682,7 +1879,7 @@ int c4_set_tapes(c4_engine *e, const double *gamma_noise, const double *uniforms
     if (!e || n_games <= 0 || !gamma_noise || !uniforms) { if (e) set_err(e->err, "c4_set_tapes: bad argument"); return C4_EINVAL; }
     if (!e->d.rng_tape) { set_err(e->err, "engine was not created with C4_RNG_TAPE"); return C4_ESTATE; }
     HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipDeviceSynchronize());
     if (e->tape_noise) (void)hipFree(e->tape_noise);
     if (e->tape_u) (void)hipFree(e->tape_u);
     e->tape_noise = e->tape_u = nullptr;
@@ -1764,7 +1961,7 @@ int c4_get_stats(c4_engine *e, c4_stats *out)
 {
     if (!e || !out) return C4_EINVAL;
     HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipDeviceSynchronize());   // launches may sit on any stream the caller passed
     const size_t G = (size_t)e->d.G;
     std::vector<uint64_t> s(G * N_STATS);
     std::vector<int32_t> stt(G);
@@ -1789,6 +1986,11 @@ int c4_get_stats(c4_engine *e, c4_stats *out)
     out->eval_cache_probes = (int64_t)t.cache_probes;
     out->bad_evals = (int64_t)t.bad_evals;
     out->launches = e->launches;
+    if (e->cold.dropped) {
+        unsigned long long dr = 0;
+        HIPCHK(e, hipMemcpy(&dr, e->cold.dropped, sizeof(dr), hipMemcpyDeviceToHost));
+        out->dropped_games = (int64_t)dr;
+    }
     for (size_t g = 0; g < G; ++g) out->active_slots += stt[g] == SLOT_ACTIVE;
     return C4_OK;
 }
@@ -1800,10 +2002,13 @@ int c4_run_centre(c4_engine *e, int32_t max_launches)
     for (int i = 0; i < max_launches; ++i) {
         int rc = c4_step(e, nullptr, nullptr, nullptr);
         if (rc) return rc;
-        c4_stats s;
-        rc = c4_get_stats(e, &s);
-        if (rc) return rc;
-        if (s.active_slots == 0) return C4_OK;
+        // four bytes back per launch: how many slots are still searching
+        hipLaunchKernelGGL(k_count_active, dim3(1), dim3(1024), 0, e->stream, e->d.state, e->d.G, e->active_dev);
+        HIPCHK(e, hipGetLastError());
+        int32_t active = 0;
+        HIPCHK(e, hipMemcpyAsync(&active, e->active_dev, sizeof(active), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (active == 0) return C4_OK;
     }
     return C4_OK;
 }
@@ -1821,7 +2026,7 @@ int c4_read_leaves(c4_engine *e, uint64_t *c0, uint64_t *c1, int32_t *has_leaf)
 {
     if (!e || !c0 || !c1 || !has_leaf) return C4_EINVAL;
     HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipDeviceSynchronize());
     const size_t G = (size_t)e->d.G;
     HIPCHK(e, hipMemcpy(c0, e->d.leaf_c0, G * sizeof(uint64_t), hipMemcpyDeviceToHost));
     HIPCHK(e, hipMemcpy(c1, e->d.leaf_c1, G * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -1835,62 +2040,14 @@ int c4_read_roots(c4_engine *e, c4_root_result *out)
     HIPCHK(e, hipSetDevice(e->device));
     c4_root_result *dout = nullptr;
     const size_t G = (size_t)e->d.G;
+    HIPCHK(e, hipDeviceSynchronize());
     HIPCHK(e, hipMalloc((void **)&dout, G * sizeof(c4_root_result)));
     hipLaunchKernelGGL(c4_gather_roots_kernel, dim3((e->d.G + 63) / 64), dim3(64), 0, e->stream, e->d, dout);
     hipError_t r = hipGetLastError();
-    if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+    if (r == hipSuccess) r = hipDeviceSynchronize();
     if (r == hipSuccess) r = hipMemcpy(out, dout, G * sizeof(c4_root_result), hipMemcpyDeviceToHost);
     (void)hipFree(dout);
     HIPCHK(e, r);
-    return C4_OK;
-}
-
-int c4_drain_games(c4_engine *e, c4_game_record *out, int32_t cap, int32_t *n_out)
-{
-    if (!e || !out || !n_out || cap < 0) return C4_EINVAL;
-    *n_out = 0;
-    const size_t R = (size_t)e->d.rec_cap;
-    if (R == 0) return C4_OK;
-    HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    std::vector<int32_t> len(R), res(R);
-    std::vector<long long> tag(R);
-    HIPCHK(e, hipMemcpy(len.data(), e->cold.game_len, R * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIPCHK(e, hipMemcpy(res.data(), e->cold.game_result, R * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIPCHK(e, hipMemcpy(tag.data(), e->cold.game_tag, R * sizeof(long long), hipMemcpyDeviceToHost));
-    // finished + not yet drained, by game id
-    std::vector<std::pair<long long, size_t>> ready;
-    for (size_t r = 0; r < R; ++r)
-        if (len[r] > 0 && tag[r] >= 0 && e->drained_tag[r] != tag[r]) ready.push_back({tag[r], r});
-    std::sort(ready.begin(), ready.end());
-    std::vector<uint64_t> b0(42), b1(42);
-    std::vector<int32_t> mv(42);
-    std::vector<double> val(42), pol(42 * 7);
-    int n = 0;
-    for (auto &pr : ready) {
-        if (n >= cap) break;
-        const size_t r = pr.second;
-        HIPCHK(e, hipMemcpy(b0.data(), e->cold.rec_c0 + r * 42, 42 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        HIPCHK(e, hipMemcpy(b1.data(), e->cold.rec_c1 + r * 42, 42 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        HIPCHK(e, hipMemcpy(mv.data(), e->cold.rec_move + r * 42, 42 * sizeof(int32_t), hipMemcpyDeviceToHost));
-        HIPCHK(e, hipMemcpy(val.data(), e->cold.rec_value + r * 42, 42 * sizeof(double), hipMemcpyDeviceToHost));
-        HIPCHK(e, hipMemcpy(pol.data(), e->cold.rec_policy + r * 42 * 7, 42 * 7 * sizeof(double), hipMemcpyDeviceToHost));
-        c4_game_record &g = out[n];
-        memset(&g, 0, sizeof(g));
-        g.game_id = pr.first;
-        g.length = len[r];
-        g.result = res[r];
-        for (int i = 0; i < len[r] && i < 42; ++i) {
-            g.color0[i] = b0[i];
-            g.color1[i] = b1[i];
-            g.move[i] = mv[i];
-            g.value[i] = val[i];
-            for (int k = 0; k < 7; ++k) g.policy[i][k] = pol[i * 7 + k];
-        }
-        e->drained_tag[r] = pr.first;
-        ++n;
-    }
-    *n_out = n;
     return C4_OK;
 }
 
@@ -1906,6 +2063,154 @@ int c4_drain_games(c4_engine *e, c4_game_record *out, int32_t cap, int32_t *n_ou
 #define BOARD_EPILOGUE()                                                                    \
     if (r != hipSuccess) { set_err(g_err, "HIP failure: %s", hipGetErrorString(r)); return C4_EDEVICE; } \
     return C4_OK;
+
+namespace {
+int ring_counters(c4_engine *e, unsigned long long &head, unsigned long long &tail)
+{
+    HIPCHK(e, hipMemcpy(&head, e->cold.ring_head, sizeof(head), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(&tail, e->cold.ring_tail, sizeof(tail), hipMemcpyDeviceToHost));
+    return C4_OK;
+}
+}  // namespace
+
+int c4_finished_games(c4_engine *e, int64_t *n_ready, int64_t *n_dropped)
+{
+    if (!e) return C4_EINVAL;
+    if (n_ready) *n_ready = 0;
+    if (n_dropped) *n_dropped = 0;
+    if (e->d.rec_cap == 0) return C4_OK;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipDeviceSynchronize());
+    unsigned long long head = 0, tail = 0, dr = 0;
+    int rc = ring_counters(e, head, tail);
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpy(&dr, e->cold.dropped, sizeof(dr), hipMemcpyDeviceToHost));
+    if (n_ready) *n_ready = (int64_t)(head - tail);
+    if (n_dropped) *n_dropped = (int64_t)dr;
+    return C4_OK;
+}
+
+int c4_drain_games(c4_engine *e, c4_game_record *out, int32_t cap, int32_t *n_out)
+{
+    if (!e || !out || !n_out || cap < 0) return C4_EINVAL;
+    *n_out = 0;
+    const unsigned long long R = (unsigned long long)e->d.rec_cap;
+    if (R == 0) return C4_OK;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipDeviceSynchronize());
+    unsigned long long head = 0, tail = 0;
+    int rc = ring_counters(e, head, tail);
+    if (rc) return rc;
+    unsigned long long n = head - tail;
+    if (n > (unsigned long long)cap) n = (unsigned long long)cap;
+    if (n == 0) return C4_OK;
+    // the rows [tail, tail+n) of the ring, at most two contiguous pieces: one or two copies for ALL games
+    const unsigned long long first = tail % R;
+    const unsigned long long n1 = std::min(n, R - first);
+    HIPCHK(e, hipMemcpy(out, e->cold.ring + first, n1 * sizeof(c4_game_record), hipMemcpyDeviceToHost));
+    if (n > n1) HIPCHK(e, hipMemcpy(out + n1, e->cold.ring, (n - n1) * sizeof(c4_game_record), hipMemcpyDeviceToHost));
+    tail += n;
+    HIPCHK(e, hipMemcpy(e->cold.ring_tail, &tail, sizeof(tail), hipMemcpyHostToDevice));
+    std::sort(out, out + n, [](const c4_game_record &a, const c4_game_record &b) { return a.game_id < b.game_id; });
+    *n_out = (int32_t)n;
+    return C4_OK;
+}
+
+int c4_export_games_dev(c4_engine *e, const c4_export_buffers *bufs, int32_t max_games, int64_t cap_positions, int64_t *counts_dev,
+                        void *hip_stream)
+{
+    if (!e || !bufs || max_games < 0 || cap_positions < 0) { if (e) set_err(e->err, "c4_export_games_dev: bad argument"); return C4_EINVAL; }
+    if (e->d.rec_cap == 0) { set_err(e->err, "engine keeps no game records (stop_after_move)"); return C4_ESTATE; }
+    if (max_games > e->d.rec_cap) max_games = e->d.rec_cap;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    hipLaunchKernelGGL(k_export_scan, dim3(1), dim3(1024), 0, st, (const Cold *)e->cold_dev, e->d.rec_cap, (int)max_games,
+                       (long long)cap_positions, e->export_scratch);
+    HIPCHK(e, hipGetLastError());
+    const int blocks = std::max(1, std::min((int)max_games, 65536));
+    hipLaunchKernelGGL(k_export_write, dim3(blocks), dim3(64), 0, st, (const Cold *)e->cold_dev, e->d.rec_cap,
+                       (const int64_t *)e->export_scratch, *bufs);
+    HIPCHK(e, hipGetLastError());
+    hipLaunchKernelGGL(k_export_commit, dim3(1), dim3(1), 0, st, (const Cold *)e->cold_dev, (const int64_t *)e->export_scratch, counts_dev);
+    HIPCHK(e, hipGetLastError());
+    return C4_OK;
+}
+
+int c4_training_tensors_dev(int device, void *hip_stream, const int64_t *boards_dev, const float *targets_dev, const float *policy_dev,
+                            int64_t n, int32_t add_fliplr, float *out_boards_dev, float *out_values_dev, float *out_priors_dev)
+{
+    if (n < 0 || !boards_dev || !targets_dev || !policy_dev || !out_boards_dev || !out_values_dev || !out_priors_dev) { set_err(g_err, "c4_training_tensors_dev: bad argument"); return C4_EINVAL; }
+    int rc = check_device(device, g_err);
+    if (rc) return rc;
+    if (n == 0) return C4_OK;
+    const long long tot = (long long)n * (add_fliplr ? 2 : 1) * 126;
+    hipLaunchKernelGGL(k_training_tensors, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, boards_dev, targets_dev,
+                       policy_dev, (long long)n, (int)add_fliplr, out_boards_dev, out_values_dev, out_priors_dev);
+    hipError_t r = hipGetLastError();
+    if (r != hipSuccess) { set_err(g_err, "k_training_tensors launch failed: %s", hipGetErrorString(r)); return C4_EDEVICE; }
+    return C4_OK;
+}
+
+int c4_eval_cache_lookup(c4_engine *e, const uint64_t *color0, const uint64_t *color1, int32_t n, float *value, float *prior, int32_t *found)
+{
+    if (!e || n < 0 || !color0 || !color1 || !value || !prior || !found) { if (e) set_err(e->err, "c4_eval_cache_lookup: bad argument"); return C4_EINVAL; }
+    if (!e->d.cache) { set_err(e->err, "this engine has no evaluation cache"); return C4_ESTATE; }
+    if (n == 0) return C4_OK;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipDeviceSynchronize());
+    hipError_t r = hipSuccess;
+    Scratch sc;
+    uint64_t *d0 = sc.up(color0, n, r), *d1 = sc.up(color1, n, r);
+    float *dv = sc.up<float>(nullptr, n, r), *dp = sc.up<float>(nullptr, (size_t)n * 7, r);
+    int32_t *df = sc.up<int32_t>(nullptr, n, r);
+    if (r == hipSuccess) {
+        hipLaunchKernelGGL(k_cache_lookup, dim3((n * GROUP + 63) / 64), dim3(64), 0, 0, e->d, d0, d1, (int)n, dv, dp, df);
+        r = hipGetLastError();
+    }
+    if (r == hipSuccess) r = hipMemcpy(value, dv, sizeof(float) * n, hipMemcpyDeviceToHost);
+    if (r == hipSuccess) r = hipMemcpy(prior, dp, sizeof(float) * (size_t)n * 7, hipMemcpyDeviceToHost);
+    if (r == hipSuccess) r = hipMemcpy(found, df, sizeof(int32_t) * n, hipMemcpyDeviceToHost);
+    HIPCHK(e, r);
+    return C4_OK;
+}
+
+int c4_debug_root_noise(int device, uint64_t seed, double alpha, const int64_t *game_id, const int32_t *ply, const int32_t *legal_mask,
+                        int32_t n, double *gamma_raw, double *dirichlet)
+{
+    if (!game_id || !ply || !legal_mask || !gamma_raw || !dirichlet || !(alpha > 0.0)) { set_err(g_err, "c4_debug_root_noise: bad argument"); return C4_EINVAL; }
+    BOARD_PROLOGUE();
+    long long *dg = (long long *)sc.up((const int64_t *)game_id, n, r);
+    int32_t *dp = sc.up(ply, n, r), *dm = sc.up(legal_mask, n, r);
+    double *draw = sc.up<double>(nullptr, (size_t)n * 7, r), *ddir = sc.up<double>(nullptr, (size_t)n * 7, r);
+    if (r == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_noise, dim3((n * GROUP + 63) / 64), dim3(64), 0, 0, seed, alpha, dg, dp, dm, (int)n, draw, ddir);
+        r = hipGetLastError();
+    }
+    if (r == hipSuccess) r = hipMemcpy(gamma_raw, draw, sizeof(double) * (size_t)n * 7, hipMemcpyDeviceToHost);
+    if (r == hipSuccess) r = hipMemcpy(dirichlet, ddir, sizeof(double) * (size_t)n * 7, hipMemcpyDeviceToHost);
+    BOARD_EPILOGUE();
+}
+
+int c4_debug_sample_move(int device, uint64_t seed, const int64_t *game_id, const int32_t *ply, const double *child_values,
+                         const int32_t *n_children, const double *uniforms, int32_t n, double *uniform_out, int32_t *choice_out)
+{
+    if (!game_id || !ply || !child_values || !n_children || !uniform_out || !choice_out) { set_err(g_err, "c4_debug_sample_move: bad argument"); return C4_EINVAL; }
+    BOARD_PROLOGUE();
+    for (int i = 0; i < n; ++i)
+        if (n_children[i] < 1 || n_children[i] > 7) { set_err(g_err, "n_children[%d]=%d out of range", i, n_children[i]); return C4_EINVAL; }
+    long long *dg = (long long *)sc.up((const int64_t *)game_id, n, r);
+    int32_t *dp = sc.up(ply, n, r), *dn = sc.up(n_children, n, r);
+    double *dv = sc.up(child_values, (size_t)n * 7, r);
+    double *du_in = uniforms ? sc.up(uniforms, n, r) : nullptr;
+    double *du = sc.up<double>(nullptr, n, r);
+    int32_t *dc = sc.up<int32_t>(nullptr, n, r);
+    if (r == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_sample, dim3((n * GROUP + 63) / 64), dim3(64), 0, 0, seed, dg, dp, dv, dn, du_in, (int)n, du, dc);
+        r = hipGetLastError();
+    }
+    if (r == hipSuccess) r = hipMemcpy(uniform_out, du, sizeof(double) * n, hipMemcpyDeviceToHost);
+    if (r == hipSuccess) r = hipMemcpy(choice_out, dc, sizeof(int32_t) * n, hipMemcpyDeviceToHost);
+    BOARD_EPILOGUE();
+}
 
 int c4_board_make_move(int device, const uint64_t *c0, const uint64_t *c1, const int32_t *col, int32_t n,
                        uint64_t *o0, uint64_t *o1, int32_t *result)

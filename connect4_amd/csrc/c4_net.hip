@@ -114,6 +114,14 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
                  F, desc->channels, desc->filters, desc->n_residuals);
         return C4_EINVAL;
     }
+    if (desc->precision != C4_NET_F16 && desc->precision != C4_NET_F32X3) {
+        snprintf(n_err, 512, "c4_net_create: unknown precision %d", desc->precision);
+        return C4_EINVAL;
+    }
+    if (desc->precision == C4_NET_F32X3) {
+        snprintf(n_err, 512, "c4_net_create: the reference-precision forward is not in this build");
+        return C4_EINVAL;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) {
         snprintf(n_err, 512, "no usable HIP device %d: the fused net has no CPU fallback", device);

@@ -141,12 +141,77 @@ class Engine:
         self._check(self._lib.c4_read_roots(self._h, out))
         return out
 
+    @property
+    def record_capacity(self):
+        return int(self.cfg.record_capacity_games or 2 * self.n_slots)
+
+    def finished_games(self):
+        """(finished games waiting in the device ring, finished games lost to a full ring)."""
+        ready, dropped = C.c_int64(), C.c_int64()
+        self._check(self._lib.c4_finished_games(self._h, C.byref(ready), C.byref(dropped)))
+        return ready.value, dropped.value
+
     def drain_games(self, cap=None):
-        cap = int(cap if cap is not None else max(1, self.cfg.record_capacity_games or 2 * self.n_slots))
+        """Host copy of the finished games (float64 values/policies, for parity tests and GameData)."""
+        ready, _ = self.finished_games()
+        cap = int(min(cap, ready) if cap is not None else ready)
+        if cap <= 0:
+            return []
         out = (L.GameRecord * cap)()
         n = C.c_int32()
         self._check(self._lib.c4_drain_games(self._h, out, cap, C.byref(n)))
         return [out[i] for i in range(n.value)]
+
+    _EXPORT_FIELDS = ("boards", "moves", "values", "policy", "targets", "game_index", "lengths", "results", "ids")
+
+    def export_buffers(self, max_games=None, cap_positions=None):
+        """Device tensors an export writes into: (dict of tensors, counts int64[2] = {games, positions})."""
+        import torch
+        max_games = min(int(max_games if max_games is not None else self.record_capacity), self.record_capacity)
+        cap_positions = int(cap_positions if cap_positions is not None else 42 * max_games)
+        dev = torch.device("cuda", self.device)
+        t = dict(boards=torch.empty((cap_positions, 2), dtype=torch.int64, device=dev),
+                 moves=torch.empty(cap_positions, dtype=torch.uint8, device=dev),
+                 values=torch.empty(cap_positions, dtype=torch.float32, device=dev),
+                 policy=torch.empty((cap_positions, 7), dtype=torch.float32, device=dev),
+                 targets=torch.empty(cap_positions, dtype=torch.float32, device=dev),
+                 game_index=torch.empty(cap_positions, dtype=torch.int32, device=dev),
+                 lengths=torch.empty(max_games, dtype=torch.int32, device=dev),
+                 results=torch.empty(max_games, dtype=torch.int8, device=dev),
+                 ids=torch.empty(max_games, dtype=torch.int64, device=dev))
+        return t, torch.zeros(2, dtype=torch.int64, device=dev)
+
+    def export_games_async(self, tensors, counts, stream=0):
+        """Queue one device-side export (c4_export_games_dev) behind the launches on `stream`: consumes the
+        finished games that fit `tensors`, writes {games, positions} to `counts`.  No host synchronisation."""
+        import torch
+        if not stream:
+            stream = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream
+        b = L.ExportBuffers(*[tensors[k].data_ptr() for k in self._EXPORT_FIELDS])
+        self._check(self._lib.c4_export_games_dev(self._h, C.byref(b), int(tensors["lengths"].shape[0]),
+                                                  int(tensors["moves"].shape[0]), C.c_void_p(counts.data_ptr()),
+                                                  C.c_void_p(stream)))
+
+    def export_games(self, max_games=None, cap_positions=None, stream=0):
+        """Device-side export: consume up to max_games finished games into torch DEVICE tensors (compact
+        record, ~50 B/position) with no per-game host work.  Returns PackedGames (connect4_amd.packed)."""
+        from .packed import PackedGames
+        t, counts = self.export_buffers(max_games, cap_positions)
+        self.export_games_async(t, counts, stream)
+        n_games, n_pos = [int(x) for x in counts.tolist()]     # the one synchronisation of the export
+        per_pos = ("boards", "moves", "values", "policy", "targets", "game_index")
+        return PackedGames(**{k: (v[:n_pos] if k in per_pos else v[:n_games]) for k, v in t.items()})
+
+    def cache_lookup(self, color0, color1):
+        """What the evaluation cache answers for the positions: (values f32[n], priors f32[n,7], found bool[n])."""
+        c0, c1 = _u64(color0), _u64(color1)
+        n = len(c0)
+        v = np.zeros(n, dtype=np.float32)
+        p = np.zeros((n, 7), dtype=np.float32)
+        f = np.zeros(n, dtype=np.int32)
+        self._check(self._lib.c4_eval_cache_lookup(self._h, _ptr(c0, C.c_uint64), _ptr(c1, C.c_uint64), n,
+                                                   _ptr(v, C.c_float), _ptr(p, C.c_float), _ptr(f, C.c_int32)))
+        return v, p, f.astype(bool)
 
 
 # -- pure board functions executed by the device code ------------------------------------------
@@ -190,6 +255,55 @@ def board_fliplr(color0, color1, device=0):
     L.check(L.load().c4_board_fliplr(device, _ptr(c0, C.c_uint64), _ptr(c1, C.c_uint64), len(c0),
                                      _ptr(o0, C.c_uint64), _ptr(o1, C.c_uint64)))
     return o0, o1
+
+
+def training_tensors(boards, targets, policy, add_fliplr=True, stream=0):
+    """native_to_pytorch (data.py:78-105) on device: torch device tensors in (int64 [n,2], f32 [n], f32 [n,7]),
+    torch device tensors out (boards F32[m,3,6,7], values F32[m], priors F32[m,7]), m = 2n with the mirrored copies."""
+    import torch
+    n = int(boards.shape[0])
+    dev = boards.device
+    m = n * (2 if add_fliplr else 1)
+    ob = torch.empty((m, 3, 6, 7), dtype=torch.float32, device=dev)
+    ov = torch.empty(m, dtype=torch.float32, device=dev)
+    op = torch.empty((m, 7), dtype=torch.float32, device=dev)
+    if n:
+        boards, targets, policy = boards.contiguous(), targets.contiguous(), policy.contiguous()
+        if not stream:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        L.check(L.load().c4_training_tensors_dev(dev.index or 0, C.c_void_p(stream), C.c_void_p(boards.data_ptr()),
+                                                 C.c_void_p(targets.data_ptr()), C.c_void_p(policy.data_ptr()), n,
+                                                 1 if add_fliplr else 0, C.c_void_p(ob.data_ptr()), C.c_void_p(ov.data_ptr()),
+                                                 C.c_void_p(op.data_ptr())))
+    return ob, ov, op
+
+
+def debug_root_noise(seed, alpha, game_id, ply, legal_mask, device=0):
+    gid = np.ascontiguousarray(game_id, dtype=np.int64)
+    pl = np.ascontiguousarray(ply, dtype=np.int32)
+    lm = np.ascontiguousarray(legal_mask, dtype=np.int32)
+    n = len(gid)
+    raw = np.zeros((n, 7))
+    dr = np.zeros((n, 7))
+    L.check(L.load().c4_debug_root_noise(device, int(seed) & 0xFFFFFFFFFFFFFFFF, float(alpha), _ptr(gid, C.c_int64), _ptr(pl, C.c_int32),
+                                         _ptr(lm, C.c_int32), n, _ptr(raw, C.c_double), _ptr(dr, C.c_double)))
+    return raw, dr
+
+
+def debug_sample_move(seed, game_id, ply, child_values, n_children, uniforms=None, device=0):
+    gid = np.ascontiguousarray(game_id, dtype=np.int64)
+    pl = np.ascontiguousarray(ply, dtype=np.int32)
+    cv = np.ascontiguousarray(child_values, dtype=np.float64)
+    nc = np.ascontiguousarray(n_children, dtype=np.int32)
+    n = len(gid)
+    assert cv.shape == (n, 7)
+    u_in = None if uniforms is None else np.ascontiguousarray(uniforms, dtype=np.float64)
+    u = np.zeros(n)
+    ch = np.zeros(n, dtype=np.int32)
+    L.check(L.load().c4_debug_sample_move(device, int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(gid, C.c_int64), _ptr(pl, C.c_int32),
+                                          _ptr(cv, C.c_double), _ptr(nc, C.c_int32),
+                                          None if u_in is None else _ptr(u_in, C.c_double), n, _ptr(u, C.c_double), _ptr(ch, C.c_int32)))
+    return u, ch
 
 
 def board_centre_value(color0, color1, device=0):

@@ -16,8 +16,15 @@ from .net import PolicyValueNet, _fold_bn
 class FusedNet:
     from_bitboards = True
 
-    def __init__(self, state_dict, device: int = 0):
+    PRECISIONS = {"f16": 0, "f32x3": 1}
+
+    def __init__(self, state_dict, device: int = 0, precision: str = "f16"):
+        """precision: "f16" = fp16 storage / fp32 accumulation (one MFMA per k-step); "f32x3" = reference
+        precision: every fp32 operand split into fp16 hi + scaled lo parts, three MFMAs per k-step."""
         import torch
+        if precision not in self.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
+        self.precision = precision
         sd = {k: v.detach().cpu() for k, v in state_dict.items()}
         cfg = PolicyValueNet.config_from_state_dict(sd)
         self.config = cfg
@@ -51,6 +58,7 @@ class FusedNet:
             pfc_w=f32(sd["policy_head.fc1.weight"]), pfc_b=f32(sd["policy_head.fc1.bias"]))
         d = L.NetDesc()
         d.channels, d.filters, d.n_residuals = cfg.channels, cfg.filters, cfg.n_residuals
+        d.precision = self.PRECISIONS[precision]
         for k, a in self._arrays.items():
             setattr(d, k, a.ctypes.data_as(C.POINTER(C.c_float)))
         d.vout_b = float(sd["value_head.fc1.bias"].reshape(-1)[0])

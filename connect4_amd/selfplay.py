@@ -30,12 +30,12 @@ class SelfPlay:
                  games_target: int = -1, record_capacity_games: int = 0, planes_dtype=torch.float32,
                  use_graph: bool = True, steps_per_graph: int = 8, max_inner_iters: int = 8,
                  eval_cache_log2_entries: int = 0, level_budget: int = 0, time_budget_cycles: int = 80000, pipeline: int = 1,
-                 fused_loop: bool = False, steps_per_launch: int = 128):
+                 fused_loop: bool = False, steps_per_launch: int = 128, rng_mode: int = L.RNG_PHILOX):
         self.net = net
         self.n_slots = n_slots
         self.config = config
         self.device = torch.device("cuda", device)
-        self.engine = Engine(n_slots, eval_mode=L.EVAL_EXTERNAL_F32, rng_mode=L.RNG_PHILOX, seed=seed,
+        self.engine = Engine(n_slots, eval_mode=L.EVAL_EXTERNAL_F32, rng_mode=rng_mode, seed=seed,
                              stop_after_move=False, games_target=games_target,
                              record_capacity_games=record_capacity_games, max_inner_iters=max_inner_iters,
                              planes_dtype=_PLANES[planes_dtype], eval_cache_log2_entries=eval_cache_log2_entries, level_budget=level_budget, time_budget_cycles=time_budget_cycles,
@@ -123,6 +123,7 @@ class SelfPlay:
             import ctypes as C
             with torch.cuda.device(self.device):
                 stream = torch.cuda.current_stream(self.device).cuda_stream
+                self.engine.set_stream(stream)     # read-outs and exports order behind these launches
                 while k > 0:
                     n = min(k, self._steps_per_launch)
                     rc = self.engine._lib.c4_selfplay_steps(self.engine._h, self.net._h, C.c_void_p(self.values.data_ptr()),
@@ -161,16 +162,11 @@ class SelfPlay:
         self.engine.close()
 
 
-def generate_games(config: MCTSConfig, net: Callable, n_games: int, n_slots: Optional[int] = None,
-                   seed: int = 0, device: int = 0, planes_dtype=torch.float32, poll_steps: int = 256,
-                   use_graph: bool = True, timeout_s: float = 3600.0) -> List[GameData]:
-    """Play n_games self-play games and return them as GameData (training_game.py:42-67), the list
-    TrainingLoop._generate_games hands to data_storage.save (training.py:131-135)."""
+def _play_to_completion(config, net, n_games, n_slots, seed, device, planes_dtype, poll_steps, use_graph, timeout_s):
     n_slots = min(n_games, n_slots or 4096)
     sp = SelfPlay(net, n_slots, config, seed=seed, device=device, games_target=n_games,
                   record_capacity_games=n_games, planes_dtype=planes_dtype, use_graph=use_graph,
                   fused_loop=bool(getattr(net, "from_bitboards", False)))
-    games: List[GameData] = []
     t0 = time.time()
     try:
         while True:
@@ -180,6 +176,41 @@ def generate_games(config: MCTSConfig, net: Callable, n_games: int, n_slots: Opt
                 break
             if time.time() - t0 > timeout_s:
                 raise TimeoutError("self-play did not finish: %r" % (st,))
+        if st["dropped_games"]:
+            raise RuntimeError("%d finished games were dropped by a full record ring" % st["dropped_games"])
+    except BaseException:
+        sp.close()
+        raise
+    return sp
+
+
+def generate_games_packed(config: MCTSConfig, net: Callable, n_games: int, n_slots: Optional[int] = None,
+                          seed: int = 0, device: int = 0, planes_dtype=torch.float32, poll_steps: int = 256,
+                          use_graph: bool = True, timeout_s: float = 3600.0):
+    """Play n_games self-play games and return them as PackedGames on the device, sorted by game id: the
+    engine packs the finished games itself (c4_export_games_dev), nothing is looped over on the host."""
+    from .packed import PackedGames
+    if n_games <= 0:
+        return PackedGames.empty(torch.device("cuda", device))
+    sp = _play_to_completion(config, net, n_games, n_slots, seed, device, planes_dtype, poll_steps, use_graph, timeout_s)
+    try:
+        packed = sp.engine.export_games(n_games)
+    finally:
+        sp.close()
+    assert packed.n_games == n_games, (packed.n_games, n_games)
+    return packed.sorted_by_id()
+
+
+def generate_games(config: MCTSConfig, net: Callable, n_games: int, n_slots: Optional[int] = None,
+                   seed: int = 0, device: int = 0, planes_dtype=torch.float32, poll_steps: int = 256,
+                   use_graph: bool = True, timeout_s: float = 3600.0) -> List[GameData]:
+    """Play n_games self-play games and return them as GameData (training_game.py:42-67), the list
+    TrainingLoop._generate_games hands to data_storage.save (training.py:131-135); float64 values and
+    policies straight from the engine's records (c4_drain_games)."""
+    if n_games <= 0:
+        return []
+    sp = _play_to_completion(config, net, n_games, n_slots, seed, device, planes_dtype, poll_steps, use_graph, timeout_s)
+    try:
         games = sp.drain()
     finally:
         sp.close()

@@ -1,7 +1,16 @@
 """Train step with the reference's recipe (oinkoink/neural/pytorch/model.py:138-169,
 200-250): SGD(momentum 0.9, weight decay 1e-4) + MultiStepLR, loss = MSE(value) + BCE(policy), 5 epochs x
-batch 4096, checkpoint dict with the three state dicts.  Stock PyTorch-ROCm; not on the hot path."""
+batch 4096 over a shuffled dataset, checkpoint dict with the three state dicts.  Stock PyTorch-ROCm; not
+on the hot path.
+
+Parity with ``ModelWrapper.train`` is pinned (tests/test_training_cpu.py against a fixture generated from
+the reference by tests/golden/gen_golden.py): batches are drawn exactly as the reference's
+``DataLoader(data, batch_size, shuffle=True)`` draws them -- same consumption of torch's global RNG,
+same permutation, same batch boundaries -- but gathered with one tensor index per batch instead of
+4096 Python ``__getitem__`` calls + collate.
+"""
 import os
+from typing import Optional
 
 import torch
 import torch.nn as nn
@@ -26,11 +35,31 @@ class ModelConfig:
         self.use_gpu = use_gpu
 
 
+def dataloader_permutation(n: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """The index order one pass of ``DataLoader(dataset_of_n, shuffle=True)`` visits, consuming torch's global
+    RNG exactly as that pass does (torch.utils.data: _BaseDataLoaderIter.__init__ draws a base seed, then
+    RandomSampler.__iter__ draws the seed of a private generator for ``randperm``)."""
+    if generator is not None:          # an explicit generator (tests): one permutation from it
+        return torch.randperm(n, generator=generator)
+    torch.empty((), dtype=torch.int64).random_()                       # DataLoader iterator: _base_seed
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())    # RandomSampler.__iter__
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.randperm(n, generator=g)
+
+
 class Trainer:
-    def __init__(self, config: ModelConfig = None, file_name: str = None):
+    """ModelWrapper's training half (model.py:138-169, 200-250).  `device`: where the net trains; default =
+    the reference's rule (cuda:0 when use_gpu and a GPU is there, model.py:143-147) -- a multi-rank caller
+    passes its own GPU."""
+
+    def __init__(self, config: ModelConfig = None, file_name: str = None, device=None):
         self.config = config or ModelConfig()
         self.net = PolicyValueNet(self.config.net_config)
-        self.device = torch.device("cuda:0" if self.config.use_gpu and torch.cuda.is_available() else "cpu")
+        if device is not None:
+            self.device = torch.device(device)
+        else:
+            self.device = torch.device("cuda:0" if self.config.use_gpu and torch.cuda.is_available() else "cpu")
         self.net.to(self.device)
         self.optimiser = torch.optim.SGD(self.net.parameters(), lr=self.config.initial_lr,
                                          momentum=self.config.momentum, weight_decay=self.config.weight_decay)
@@ -45,15 +74,18 @@ class Trainer:
         self.net.eval()
 
     def train(self, boards, values, priors, generator=None):
-        """One generation: n_training_epochs passes over (boards F32[N,3,6,7], values F32[N], priors F32[N,7])."""
-        n = boards.shape[0]
+        """One generation (model.py:200-240): n_training_epochs shuffled passes over (boards F32[N,3,6,7],
+        values F32[N], priors F32[N,7]) -- tensors on any device; they are moved to the trainer's device once.
+        Returns the last batch's loss."""
+        n = int(boards.shape[0])
+        boards, values, priors = boards.to(self.device), values.to(self.device), priors.to(self.device)
         self.net.train()
         last = None
         for _ in range(self.config.n_training_epochs):
-            perm = torch.randperm(n, generator=generator)
+            perm = dataloader_permutation(n, generator).to(self.device)
             for i in range(0, n, self.config.batch_size):
                 idx = perm[i:i + self.config.batch_size]
-                b, v, p = boards[idx].to(self.device), values[idx].to(self.device), priors[idx].to(self.device)
+                b, v, p = boards[idx], values[idx], priors[idx]
                 self.optimiser.zero_grad()
                 xv, xp = self.net(b)
                 loss = self.value_loss(xv, v) + self.prior_loss(xp, p)   # model.py:221-225

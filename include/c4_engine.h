@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define C4_ABI_VERSION 1
+#define C4_ABI_VERSION 2
 
 /* error codes */
 #define C4_OK 0
@@ -76,7 +76,10 @@ typedef struct {
                                           mcts.py:78-88); 0: continuous self-play (training_game.py:8-19) */
     int64_t games_target;              /* self-play: slots park once this many games were started;
                                           <0 = unbounded (bench) */
-    int32_t record_capacity_games;     /* ring of finished-game records kept on device */
+    int32_t record_capacity_games;     /* rows of the device ring of finished games (completion order).  Moves
+                                          are staged per slot while a game is in flight and copied to a ring row
+                                          when it ends; a game that finds every row unread is dropped and counted
+                                          (c4_stats.dropped_games), never mixed with another game.  0 = 2 x n_slots */
     int32_t max_inner_iters;           /* cap on simulations a slot may complete inside one step call
                                           without needing the evaluator (terminal or cached leaves);
                                           bounds the duration of c4_step and of one tree call inside
@@ -122,6 +125,8 @@ typedef struct {
     int64_t bad_evals;          /* evaluator answers that were not finite / out of range and were replaced
                                    (value 0.5, prior 0; an all-zero prior becomes uniform) -- the reference
                                    asserts instead (model.py:258-263); must be 0 in a healthy run */
+    int64_t dropped_games;      /* finished games that found the record ring full (nobody drained or exported
+                                   for record_capacity_games games) and were not recorded; 0 in a healthy run */
 } c4_stats;
 
 /* Root read-out of one slot (tree.py:66-117; what MCTS.make_move returns, mcts.py:88). */
@@ -207,8 +212,56 @@ int c4_read_leaves(c4_engine *e, uint64_t *color0, uint64_t *color1, int32_t *ha
 /* -- read-out ------------------------------------------------------------------------------- */
 int c4_get_stats(c4_engine *e, c4_stats *out);                 /* synchronous */
 int c4_read_roots(c4_engine *e, c4_root_result *out /* [n_slots] */);   /* synchronous */
-/* Finished games not yet drained, in game-id order (training.py:131 games.extend). */
+/* Up to `cap` finished games not yet consumed (oldest first; the batch is returned sorted by game id;
+ * training.py:131 games.extend).  One or two device-to-host copies for the whole batch. */
 int c4_drain_games(c4_engine *e, c4_game_record *out, int32_t cap, int32_t *n_out);
+/* Finished games waiting in the ring / finished games lost to a full ring.  Synchronous. */
+int c4_finished_games(c4_engine *e, int64_t *n_ready, int64_t *n_dropped);
+
+/* Device-side export: pack up to max_games finished games (oldest first, whole games only, at most
+ * cap_positions positions) into caller-owned DEVICE buffers and consume them -- no host round trip, so
+ * it can be queued behind c4_selfplay_steps on the same stream.  Layout = the compact record of
+ * SURVEY.md 8e (what training_game.py:42-67 GameData holds, ~50 B/position); any pointer may be NULL.
+ * counts_dev (device int64[2], may be NULL) receives {games, positions} exported.
+ * Stands in for pool.imap_unordered(...) / games.extend (training.py:122-131) + the per-position
+ * Python of TrainingDataStorage.save (data.py:52-64). */
+typedef struct {
+    int64_t *boards_dev;      /* [cap_positions][2]  color0, color1 of the board BEFORE the move */
+    uint8_t *moves_dev;       /* [cap_positions] */
+    float   *values_dev;      /* [cap_positions]     child.data.absolute_value (NaN if None) */
+    float   *policy_dev;      /* [cap_positions][7]  tree.get_values_policy() */
+    float   *targets_dev;     /* [cap_positions]     game result value (create_training_values) */
+    int32_t *game_index_dev;  /* [cap_positions]     index of the position's game inside this export */
+    int32_t *lengths_dev;     /* [max_games] */
+    int8_t  *results_dev;     /* [max_games]         C4_RESULT_* */
+    int64_t *ids_dev;         /* [max_games] */
+} c4_export_buffers;
+int c4_export_games_dev(c4_engine *e, const c4_export_buffers *bufs, int32_t max_games, int64_t cap_positions,
+                        int64_t *counts_dev, void *hip_stream);
+/* native_to_pytorch(boards, values, priors, add_fliplr) (data.py:78-105) on device: boards
+ * float32 [m][3][6][7] (board.py:147-154), values float32 [m], priors float32 [m][7], m = n or 2n with
+ * the left-right mirrored copies after the originals (board.py:115-145, priors reversed). */
+int c4_training_tensors_dev(int device, void *hip_stream, const int64_t *boards_dev, const float *targets_dev,
+                            const float *policy_dev, int64_t n, int32_t add_fliplr, float *out_boards_dev,
+                            float *out_values_dev, float *out_priors_dev);
+
+/* Read-out of the evaluation cache (the memo table of evaluators.py:9-25): what it answers for the given
+ * positions.  found[i] = 0 when the position is absent (never evaluated, or evicted).  Synchronous.
+ * Lets a test replay device games on the oracle with exactly the evaluations the device used. */
+int c4_eval_cache_lookup(c4_engine *e, const uint64_t *color0, const uint64_t *color1, int32_t n, float *value,
+                         float *prior /* [n][7] */, int32_t *found);
+
+/* Read-outs of the PRODUCTION random streams (C4_RNG_PHILOX), computed by the very device functions the
+ * engine's kernels call, for statistical tests: the root noise of (seed, game id, ply) -- gamma_raw[n][7] =
+ * Gamma(alpha,1) draws (mcts.py:175-177), dirichlet[n][7] = zeroed on illegal columns and normalised
+ * (mcts.py:178) -- and the sampled opening move (tree.py:75-82): child index chosen among n_children
+ * values (from the root mover's side, child k in lane k) with the engine's uniform of (seed, game id, ply),
+ * or with uniforms[i] when given. */
+int c4_debug_root_noise(int device, uint64_t seed, double alpha, const int64_t *game_id, const int32_t *ply,
+                        const int32_t *legal_mask, int32_t n, double *gamma_raw, double *dirichlet);
+int c4_debug_sample_move(int device, uint64_t seed, const int64_t *game_id, const int32_t *ply,
+                         const double *child_values /* [n][7] */, const int32_t *n_children,
+                         const double *uniforms /* may be NULL */, int32_t n, double *uniform_out, int32_t *choice_out);
 
 /* -- pure board functions, executed by the device code (bit-exact parity tests) ------------- */
 /* board.py:160-170 make_move + result */
@@ -238,8 +291,12 @@ int c4_board_centre_value(int device, const uint64_t *color0, const uint64_t *co
  *   vout_w [42], vout_b                        value_head.fc1 (model.py:72,85)
  *   pfc_w [7][84], pfc_b [7]                   policy_head.fc1 (model.py:104,113)
  *   w1, w2                                     value_head.w1/w2 (model.py:74-75,88) */
+/* arithmetic of the fused forwards */
+#define C4_NET_F16 0    /* fp16 storage, fp32 accumulation: one v_mfma_f32_32x32x16_f16 per k-step */
+#define C4_NET_F32X3 1  /* reference precision: fp32 operands split into fp16 hi + scaled lo, three MFMAs per k-step */
 typedef struct {
-    int32_t channels, filters, n_residuals, reserved;
+    int32_t channels, filters, n_residuals;
+    int32_t precision;   /* C4_NET_F16 or C4_NET_F32X3 */
     const float *stem_w, *stem_b, *conv_w, *conv_b, *head_w, *head_b;
     const float *vfc_w, *vfc_b, *vout_w, *pfc_w, *pfc_b;
     float vout_b, w1, w2, reserved2;

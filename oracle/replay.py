@@ -1,0 +1,49 @@
+"""Replay of device self-play games on the CPU oracle (TEST INFRASTRUCTURE ONLY: tests/ and
+__graft_entry__.smoke() import this; connect4_amd/ never does).
+
+The device plays with injected RNG tapes (C4_RNG_TAPE); the oracle replays the same game with the same
+tapes while its evaluator answers with what the DEVICE's evaluation cache holds for each position
+(c4_eval_cache_lookup; the net itself for a position the direct-mapped table has since evicted).  Moves,
+float64 values, float64 policies and the result must be identical (mcts.py:94-121, training_game.py:8-19).
+"""
+import numpy as np
+
+from . import c4oracle as oc
+
+
+def random_tapes(n_games, alpha, seed):
+    """[games][42][7] raw Gamma(alpha,1) draws (mcts.py:175-177) and [games][42] uniforms (tree.py:80)."""
+    rng = np.random.RandomState(seed)
+    return rng.gamma(alpha, 1.0, size=(n_games, 42, 7)), rng.random_sample((n_games, 42))
+
+
+def oracle_config(cfg):
+    return oc.make_config(cfg.simulations, cfg.pb_c_base, cfg.pb_c_init, cfg.root_dirichlet_alpha,
+                          cfg.root_exploration_fraction, cfg.num_sampling_moves)
+
+
+def replay_game(ocfg, engine, net, rec, noise, u):
+    """Asserts that the oracle plays exactly `rec` (a c4_game_record).  Returns dict(lookups, evicted)."""
+    stats = dict(lookups=0, evicted=0)
+    memo = {}
+
+    def fn(c0, c1):
+        k = (c0, c1)
+        if k not in memo:
+            v, p, found = engine.cache_lookup([c0], [c1])
+            stats["lookups"] += 1
+            if not found[0]:
+                stats["evicted"] += 1
+                v, p = net.evaluate_bits([c0], [c1], wave=True)
+            memo[k] = (float(np.float32(v[0])), [float(x) for x in np.asarray(p[0], dtype=np.float32)])
+        v, p = memo[k]
+        return v, p, True
+    g = oc.selfplay_game(ocfg, oc.CallbackEvaluator(fn), noise, u)
+    n = rec.length
+    assert g["moves"] == list(rec.move[:n]), "moves differ from the oracle's"
+    assert g["boards"] == [(int(rec.color0[i]), int(rec.color1[i])) for i in range(n)]
+    assert g["result"] == rec.result
+    for i in range(n):
+        assert (np.isnan(g["values"][i]) and np.isnan(rec.value[i])) or g["values"][i] == rec.value[i], "values differ"
+        assert g["policies"][i] == list(rec.policy[i]), "policies differ"
+    return stats

@@ -216,7 +216,8 @@ def test_mini_generation_selfplay_train_reload(tmp_path):
     games0, loss0 = run_generation(tr, MCTSConfig.self_play(24), n_games=48, save_dir=str(tmp_path), gen=0, n_slots=48)
     assert len(games0) == 48 and loss0 is not None and loss0 == loss0
     d = torch.load(os.path.join(str(tmp_path), "0", "data.pth"), weights_only=True)
-    n_pos = sum(len(g.moves) for g in games0)
+    n_pos = games0.n_positions
+    assert n_pos == int(games0.lengths.sum()) and sorted(games0.ids.tolist()) == list(range(48))
     assert d["boards"].shape == (2 * n_pos, 3, 6, 7) and d["values"].shape == (2 * n_pos,) and d["priors"].shape == (2 * n_pos, 7)
     assert os.path.exists(os.path.join(str(tmp_path), "0", "net.pth"))
     assert not torch.equal(w0, tr.net.state_dict()["body.0.0.weight"].cpu())

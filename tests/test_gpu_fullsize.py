@@ -1,0 +1,86 @@
+"""BASELINE shapes at FULL size under -m gpu.
+
+(i)  configs[1]: 4096 games x 800 simulations on the PRODUCTION path -- c4_selfplay_wave_kernel + the 2^28-entry
+     evaluation cache + the fused MFMA net -- with injected RNG tapes, then a sample of the finished games is
+     replayed move for move on the CPU oracle, whose evaluator answers with what the device's evaluation cache
+     holds for each position (c4_eval_cache_lookup; FusedNet for a position the direct-mapped table has since
+     evicted).  Moves, float64 values, float64 policies and results must be IDENTICAL.
+     Reference: mcts.py:94-121, training_game.py:8-19.
+(ii) configs[3]: 8192 searches x 3200 simulations (deep trees) with the in-kernel centre evaluator, a sample
+     against the oracle: visit counts and float64 value sums identical.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config1_4096_games_800_sims_fused_kernel_vs_oracle(oracle):
+    from connect4_amd import _lib as L
+    from connect4_amd.config import MCTSConfig
+    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.net import random_init_state_dict
+    from connect4_amd.selfplay import SelfPlay
+    G, S = 4096, 800
+    cfg = MCTSConfig.self_play(S)
+    net = FusedNet(random_init_state_dict(seed=0))
+    sp = SelfPlay(net, G, cfg, seed=0, games_target=G, record_capacity_games=G, use_graph=False, fused_loop=True,
+                  steps_per_launch=128, rng_mode=L.RNG_TAPE)
+    from oracle.replay import oracle_config, random_tapes, replay_game
+    noise, u = random_tapes(G, cfg.root_dirichlet_alpha, seed=123)
+    sp.engine.set_tapes(noise, u)
+    sp.engine.reset()
+    for _ in range(2000):
+        sp.run_steps(256)
+        st = sp.stats()
+        if st["active_slots"] == 0:
+            break
+    assert st["active_slots"] == 0 and st["games_finished"] == G and st["dropped_games"] == 0 and st["bad_evals"] == 0
+    assert st["simulations"] == S * st["moves"]
+    recs = sp.engine.drain_games()
+    assert len(recs) == G and [r.game_id for r in recs] == list(range(G))
+    lengths = np.array([r.length for r in recs])
+    rng = np.random.RandomState(5)
+    sample = set(rng.choice(G, size=12, replace=False).tolist())
+    sample |= {int(np.argmax(lengths)), int(np.argmin(lengths))}          # the longest and the shortest game too
+    ocfg = oracle_config(cfg)
+    lookups = evicted = 0
+    for gid in sorted(sample):
+        s = replay_game(ocfg, sp.engine, net, recs[gid], noise[gid], u[gid])
+        lookups += s["lookups"]
+        evicted += s["evicted"]
+    assert lookups > 1000 and evicted <= 0.02 * lookups       # the table really is what answered
+    sp.close()
+    net.close()
+
+
+def test_config4_8192_searches_3200_sims_vs_oracle(oracle):
+    from connect4_amd import _lib as L
+    from connect4_amd.engine import Engine
+    G, S = 8192, 3200
+    rng = np.random.RandomState(0)
+    boards = []
+    while len(boards) < G:
+        b = oracle.Board.empty()
+        for _ in range(int(rng.randint(0, 12))):
+            m = b.valid_mask()
+            if not m:
+                break
+            b.make_move(int(rng.choice([c for c in range(7) if (m >> c) & 1])))
+        if b.result == oracle.NONE:
+            boards.append(b)
+    with Engine(G, S, eval_mode=L.EVAL_CENTRE, stop_after_move=True) as eng:
+        eng.reset([b.key()[0] for b in boards], [b.key()[1] for b in boards])
+        eng.run_centre(max_launches=8)
+        st = eng.stats()
+        roots = eng.read_roots()
+    assert st["active_slots"] == 0 and st["simulations"] == G * S and st["moves"] == G
+    cfg = oracle.make_config(S)
+    exp = 0
+    for i in rng.choice(G, size=32, replace=False):
+        info, mv, _ = oracle.search_and_pick(cfg, boards[i], oracle.CentreEvaluator())
+        assert list(roots[i].child_visits) == list(info.child_visits), i
+        assert list(roots[i].child_value_sum) == list(info.child_value_sum), i
+        assert roots[i].move == mv and roots[i].expansions == info.n_expansions
+        exp += info.n_expansions
+    assert exp > 0

@@ -1,0 +1,148 @@
+"""Finished-game records on the GPU: per-slot staging + ring of finished games (no two live games can
+share a row, overflow is counted, never silent), the one-copy host drain, the device-side export into
+packed tensors, the on-device training tensors, and the evaluation-cache read-out."""
+import numpy as np
+import pytest
+
+from conftest import load_json, load_npz
+
+pytestmark = pytest.mark.gpu
+
+
+def _selfplay(n_slots, sims, games_target, rec_cap, seed=3, **kw):
+    from connect4_amd.config import MCTSConfig
+    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.net import random_init_state_dict
+    from connect4_amd.selfplay import SelfPlay
+    net = FusedNet(random_init_state_dict(seed=0))
+    sp = SelfPlay(net, n_slots, MCTSConfig.self_play(sims), seed=seed, games_target=games_target,
+                  record_capacity_games=rec_cap, use_graph=False, fused_loop=True, steps_per_launch=16, **kw)
+    return sp, net
+
+
+def _check_game_on_oracle(oracle, rec):
+    """A drained record is ONE legal, complete game: boards chain through the recorded moves to the result."""
+    b = oracle.Board.empty()
+    for i in range(rec.length):
+        assert b.key() == (int(rec.color0[i]), int(rec.color1[i])), "plies of two games mixed in one record"
+        assert (b.valid_mask() >> rec.move[i]) & 1
+        assert abs(sum(rec.policy[i]) - 1.0) < 1e-9
+        b.make_move(int(rec.move[i]))
+    assert b.result == rec.result and rec.result in (0, 1, 2)
+
+
+def test_continuous_mode_periodic_drain_never_mixes_games(oracle):
+    """games_target=-1 (continuous), a ring far smaller than the number of games played, short and long games
+    in flight together, periodic drains: every drained game replays on the oracle, ids are unique, and
+    finished == drained + waiting + dropped at every point."""
+    sp, net = _selfplay(64, 20, -1, 48)
+    seen, total_dropped = {}, 0
+    for it in range(60):
+        sp.run_steps(48)
+        if it % 3 == 2:
+            for r in sp.engine.drain_games():
+                assert r.game_id not in seen
+                seen[r.game_id] = r.length
+                _check_game_on_oracle(oracle, r)
+        st = sp.stats()
+        ready, dropped = sp.engine.finished_games()
+        assert st["dropped_games"] == dropped
+        assert st["games_finished"] == len(seen) + ready + dropped
+        total_dropped = dropped
+    assert len(seen) > 200 and len(set(seen.values())) > 5      # many games, many different lengths
+    # without draining the ring fills up: further games are counted as dropped, the rows stay intact
+    for _ in range(40):
+        sp.run_steps(48)
+    ready, dropped = sp.engine.finished_games()
+    assert ready == 48 and dropped > total_dropped
+    for r in sp.engine.drain_games():
+        _check_game_on_oracle(oracle, r)
+    sp.close()
+    net.close()
+
+
+def test_device_export_equals_host_drain():
+    """Same seed twice: games read through c4_drain_games (float64) and through c4_export_games_dev (packed
+    float32 tensors written by the device) are the same games; the on-device training tensors equal the host
+    writer's (which is pinned to the reference's native_to_pytorch by test_data_writer_matches_reference...)."""
+    import torch
+    from connect4_amd.data import games_to_arrays
+    from connect4_amd.packed import PackedGames
+    outs = []
+    for mode in ("drain", "export"):
+        sp, net = _selfplay(48, 24, 120, 120, seed=9)
+        for _ in range(400):
+            sp.run_steps(64)
+            if sp.stats()["active_slots"] == 0:
+                break
+        assert sp.stats()["dropped_games"] == 0
+        if mode == "drain":
+            outs.append(sorted(sp.drain(), key=lambda g: g.game_id))
+        else:
+            first = sp.engine.export_games(max_games=50)          # two partial exports: whole games only
+            rest = sp.engine.export_games()
+            assert first.n_games == 50 and rest.n_games == 70 and sp.engine.finished_games()[0] == 0
+            outs.append(PackedGames.cat([first, rest]).sorted_by_id())
+        sp.close()
+        net.close()
+    games, packed = outs
+    assert packed.n_games == 120 and packed.ids.tolist() == list(range(120))
+    assert packed.lengths.tolist() == [len(g.moves) for g in games]
+    assert packed.results.tolist() == [int(g.result.value * 2) for g in games]
+    ref = PackedGames.from_game_data(games)
+    assert torch.equal(packed.boards.cpu(), ref.boards)
+    assert torch.equal(packed.moves.cpu(), ref.moves)
+    assert torch.equal(packed.values.cpu().nan_to_num(nan=-1.0), ref.values.nan_to_num(nan=-1.0))
+    assert torch.equal(packed.policy.cpu(), ref.policy)
+    assert torch.equal(packed.targets.cpu(), ref.targets)
+    assert torch.equal(packed.game_index.cpu(), ref.game_index)
+    # object form round trip
+    again = packed.to_game_data()
+    assert [g.moves for g in again] == [g.moves for g in games]
+    assert [[b.to_int_tuple() for b in g.boards] for g in again] == [[b.to_int_tuple() for b in g.boards] for g in games]
+    # training tensors built on the device == the host writer
+    b, v, p = packed.training_tensors(add_fliplr=True)
+    hb, hv, hp = games_to_arrays(games, add_fliplr=True)
+    assert np.array_equal(b.cpu().numpy(), hb) and np.array_equal(v.cpu().numpy(), hv) and np.array_equal(p.cpu().numpy(), hp)
+
+
+def test_training_tensors_dev_against_reference_fixture():
+    """c4_training_tensors_dev vs native_to_pytorch(add_fliplr=True) of the unmodified reference (data.py:78-105)."""
+    import torch
+    from connect4_amd.board import Board
+    from connect4_amd.packed import PackedGames
+    from connect4_amd.training_game import GameData
+    from connect4_amd.utils import Result
+    npz = load_npz("selfplay_net_tables.npz")
+    for g in load_json("selfplay_net.json"):
+        gd = GameData()
+        for bb, mv, v, p in zip(g["boards"], g["moves"], g["values"], g["policies"]):
+            gd.add_move(Board.from_bits(*bb), mv, v, np.array(p))
+        gd.result = Result(g["result"])
+        gd.game_id = 0
+        b, v, p = PackedGames.from_game_data([gd]).to(torch.device("cuda", 0)).training_tensors(True)
+        assert np.array_equal(b.cpu().numpy().astype(np.uint8), npz[g["name"] + "__data_boards"])
+        assert np.array_equal(v.cpu().numpy(), npz[g["name"] + "__data_values"])
+        assert np.array_equal(p.cpu().numpy(), npz[g["name"] + "__data_priors"])
+
+
+def test_eval_cache_lookup_returns_the_nets_answers():
+    """c4_eval_cache_lookup: every root of a finished game was evaluated, so (unless evicted) the cache
+    answers for it -- with exactly the bits the wave-private forward produces; unknown positions are absent."""
+    sp, net = _selfplay(32, 24, 64, 64, seed=4)
+    for _ in range(400):
+        sp.run_steps(64)
+        if sp.stats()["active_slots"] == 0:
+            break
+    recs = sp.engine.drain_games()
+    c0 = np.array([r.color0[i] for r in recs for i in range(r.length)], dtype=np.uint64)
+    c1 = np.array([r.color1[i] for r in recs for i in range(r.length)], dtype=np.uint64)
+    v, p, found = sp.engine.cache_lookup(c0, c1)
+    assert found.mean() > 0.95
+    nv, npri = net.evaluate_bits(c0, c1, wave=True)
+    assert np.array_equal(v[found], nv[found]) and np.array_equal(p[found], npri[found])
+    # a position no game reaches under gravity rules is never in the table
+    _, _, f2 = sp.engine.cache_lookup(np.array([1 << 5], dtype=np.uint64), np.array([1 << 40], dtype=np.uint64))
+    assert not f2[0]
+    sp.close()
+    net.close()

@@ -129,7 +129,7 @@ def test_training_tensors_dev_against_reference_fixture():
 def test_eval_cache_lookup_returns_the_nets_answers():
     """c4_eval_cache_lookup: every root of a finished game was evaluated, so (unless evicted) the cache
     answers for it -- with exactly the bits the wave-private forward produces; unknown positions are absent."""
-    sp, net = _selfplay(32, 24, 64, 64, seed=4)
+    sp, net = _selfplay(32, 24, 64, 64, seed=4, eval_cache_log2_entries=22)   # roomy table: hardly any collision
     for _ in range(400):
         sp.run_steps(64)
         if sp.stats()["active_slots"] == 0:

@@ -18,6 +18,9 @@ What is written (all data: inputs + expected outputs, no reference source text):
                       evaluator's position_table so that tree logic replays without conv numerics
   selfplay.json / selfplay_net.npz   training_game() with recorded RNG tapes
   net_golden.npz      example_net.pth weights (data file) + ModelWrapper outputs on fixed positions
+  train_step.npz      ModelWrapper.train (model.py:200-240) on a seeded net and a small seeded dataset:
+                      initial weights, the dataset, torch seed, final weights / BN statistics / momentum
+                      (`python gen_golden.py train` regenerates only this file)
 """
 import json
 import os
@@ -323,7 +326,48 @@ def dump_net(model):
     np.savez_compressed(os.path.join(OUT, "net_golden.npz"), **blobs)
 
 
+# ---------------------------------------------------------------- train step
+def dump_train_step():
+    """One generation of the reference's training recipe on CPU, everything seeded."""
+    from oinkoink.neural.pytorch.data import Connect4Dataset
+    torch.set_num_threads(1)
+    torch.manual_seed(7)
+    cfg = ModelConfig(use_gpu=False, batch_size=64, n_training_epochs=2)
+    model = ModelWrapper(cfg)                                   # seeded random init
+    blobs = {"init__" + k: v.detach().clone().numpy() for k, v in model.net.state_dict().items()}
+    rng = np.random.RandomState(3)
+    n = 200                                                     # 3 full batches + a ragged one of 8
+    boards = [random_position(rng, int(rng.randint(0, 38))) for _ in range(n)]
+    bt = torch.FloatTensor(np.stack([b.to_array() for b in boards]))
+    vt = torch.FloatTensor(rng.choice([0.0, 0.5, 1.0], size=n))
+    pt = torch.FloatTensor(rng.dirichlet(np.ones(7), size=n))
+    blobs["data_boards"] = bt.numpy().astype(np.uint8)
+    blobs["data_values"] = vt.numpy()
+    blobs["data_priors"] = pt.numpy()
+    blobs["torch_seed"] = np.array([99], dtype=np.int64)
+    blobs["config"] = np.array([cfg.batch_size, cfg.n_training_epochs], dtype=np.int64)
+    torch.manual_seed(99)
+    model.train(Connect4Dataset(bt, vt, pt))
+    for k, v in model.net.state_dict().items():
+        blobs["final__" + k] = v.detach().clone().numpy()
+    names = [k for k, _ in model.net.named_parameters()]
+    for k, p in zip(names, model.net.parameters()):
+        st = model.optimiser.state.get(p, {})
+        if "momentum_buffer" in st and st["momentum_buffer"] is not None:
+            blobs["momentum__" + k] = st["momentum_buffer"].detach().clone().numpy()
+    blobs["lr_after"] = np.array([g["lr"] for g in model.optimiser.param_groups], dtype=np.float64)
+    with torch.no_grad():
+        xv, xp = model.net(bt[:32])
+    blobs["eval_values"] = xv.numpy()
+    blobs["eval_priors"] = xp.numpy()
+    np.savez_compressed(os.path.join(OUT, "train_step.npz"), **blobs)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "train":
+        dump_train_step()
+        print("train_step.npz written to", OUT)
+        return
     torch.manual_seed(0)
     torch.set_num_threads(1)  # deterministic accumulation order for the recorded net outputs
     ref_tests = dump_ref_tests()
@@ -333,6 +377,7 @@ def main():
     dump_net(model)
     dump_search_net(model)
     dump_selfplay(model)
+    dump_train_step()
     print("golden fixtures written to", OUT)
 
 

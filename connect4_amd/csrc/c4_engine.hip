@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
 // bit-identical to net_forward_block's).
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(4))) const Dev const_dev;
-template <int TS>
+template <int TS, bool PRECISE>
 __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const Dev *d_dev, c4net::NetDev nd, float *__restrict__ values,
                                                                            float *__restrict__ priors, int n_steps)
 {
@@ -1271,13 +1271,20 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
             const int has = __builtin_amdgcn_readfirstlane(smem[sq].has_leaf() ? 1 : 0);
             if (has) pend_slot[cnt++] = sq;
         }
-        for (int i = 0; i < cnt; i += WP) {
-            const int sa = pend_slot[i], sb = pend_slot[i + 1 < cnt ? i + 1 : i];
-            net_forward_wave(nd, &act[wv][0][0], &act[wv][1][0], mlp, s_bias, smem[sa].leaf0, smem[sa].leaf1, smem[sb].leaf0,
-                             smem[sb].leaf1, min(WP, cnt - i), s_val, s_pri, sa, sb);
+        if (PRECISE) {   // reference-precision net (C4_NET_F32X3): one position per pass
+            for (int i = 0; i < cnt; ++i) {
+                const int sa = pend_slot[i];
+                net_forward_wave_precise(nd, &act[wv][0][0], mlp, s_bias, smem[sa].leaf0, smem[sa].leaf1, s_val, s_pri, sa);
+            }
+        } else {
+            for (int i = 0; i < cnt; i += WP) {
+                const int sa = pend_slot[i], sb = pend_slot[i + 1 < cnt ? i + 1 : i];
+                net_forward_wave(nd, &act[wv][0][0], &act[wv][1][0], mlp, s_bias, smem[sa].leaf0, smem[sa].leaf1, smem[sb].leaf0,
+                                 smem[sb].leaf1, min(WP, cnt - i), s_val, s_pri, sa, sb);
+            }
         }
         lds_fence();   // answers (LDS) before the next tree_step reads them
-        if (d.has_stamps) { t_tree += tb - ta; t_net += __builtin_amdgcn_s_memtime() - tb; n_pass += (cnt + WP - 1) / WP; }
+        if (d.has_stamps) { t_tree += tb - ta; t_net += __builtin_amdgcn_s_memtime() - tb; n_pass += PRECISE ? cnt : (cnt + WP - 1) / WP; }
     }
     if (d.has_stamps && blockIdx.x < 128 && (threadIdx.x & 63) == 0) {   // per wave: tree cycles, net cycles | passes << 48
         d.cold->stamps[blockIdx.x * 16 + wv] = t_tree;
@@ -1938,10 +1945,17 @@ int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *prior
             HIPCHK(e, hipStreamSynchronize(st));   // the source is a member that may change right after this call
             e->d_uploaded = e->d;
         }
-        if (e->fused_slots == 32)
-            hipLaunchKernelGGL(c4_selfplay_wave_kernel<32>, dim3((e->d.G + 31) / 32), dim3(c4net::NTHREADS), 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps);
+        const dim3 g32((e->d.G + 31) / 32), g16((e->d.G + 15) / 16), blk(c4net::NTHREADS);
+        if (nd.precise) {
+            if (e->fused_slots == 32) hipLaunchKernelGGL((c4_selfplay_wave_kernel<32, true>), g32, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps);
+            else hipLaunchKernelGGL((c4_selfplay_wave_kernel<16, true>), g16, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps);
+        } else if (e->fused_slots == 32)
+            hipLaunchKernelGGL((c4_selfplay_wave_kernel<32, false>), g32, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps);
         else
-            hipLaunchKernelGGL(c4_selfplay_wave_kernel<16>, dim3((e->d.G + 15) / 16), dim3(c4net::NTHREADS), 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps);
+            hipLaunchKernelGGL((c4_selfplay_wave_kernel<16, false>), g16, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps);
+    } else if (nd.precise) {
+        set_err(e->err, "C4_FUSED_MODE=block has no reference-precision forward; use the default wave-autonomous kernel");
+        return C4_ESTATE;
     } else if (e->fused_slots == 32)
         hipLaunchKernelGGL(c4_selfplay_kernel<32>, dim3((e->d.G + 31) / 32), dim3(c4net::NTHREADS), 0, st, e->d, nd, values_dev, priors_dev, (int)n_steps);
     else

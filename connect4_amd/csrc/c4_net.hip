@@ -75,6 +75,26 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_wave_kernel(NetDev nd, const 
                      values, priors, pA, pB, (nd.stamps && blockIdx.x == 0) ? nd.stamps + wv * 16 : nullptr);
 }
 
+// Reference-precision forward (C4_NET_F32X3, net_forward_wave_precise): one position per wave.  Both
+// c4_net_forward and c4_net_forward_wave run this kernel for a precise net (one implementation, so the two
+// entry points and the fused self-play kernel cannot disagree).
+__global__ __launch_bounds__(NTHREADS) void c4_net_wave_precise_kernel(NetDev nd, const uint64_t *__restrict__ c0,
+                                                                       const uint64_t *__restrict__ c1, int n,
+                                                                       float *__restrict__ values, float *__restrict__ priors)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 act[NWAVES][2][WACT];
+    __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
+    __shared__ __attribute__((aligned(16))) float s_bias[BIAS_LDS_FLOATS];
+    for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
+    stage_bias_lds(nd, s_bias);
+    __syncthreads();
+    const int wv = threadIdx.x >> 6;
+    const int p = blockIdx.x * NWAVES + wv;
+    if (p >= n) return;
+    net_forward_wave_precise(nd, &act[wv][0][0], mlp, s_bias, c0[p], c1[p], values, priors, p,
+                             (nd.stamps && blockIdx.x == 0) ? nd.stamps + wv * 16 : nullptr);
+}
+
 thread_local char n_err[512] = "";
 
 }  // namespace
@@ -118,10 +138,6 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
         snprintf(n_err, 512, "c4_net_create: unknown precision %d", desc->precision);
         return C4_EINVAL;
     }
-    if (desc->precision == C4_NET_F32X3) {
-        snprintf(n_err, 512, "c4_net_create: the reference-precision forward is not in this build");
-        return C4_EINVAL;
-    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) {
         snprintf(n_err, 512, "no usable HIP device %d: the fused net has no CPU fallback", device);
@@ -133,13 +149,19 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
     const int R = desc->n_residuals;
     // ---- stem: A[cout][k], k = tap*4 + ch (ch 3 zero), 48 = 3 k-steps; lane l holds cout l&31, k = 16s + 8(l>>5) + j
     std::vector<_Float16> stem(3 * 64 * 8), conv((size_t)2 * R * KSTEPS * 64 * 8), head(2 * 64 * 8);
+    // reference-precision mode: w ~= hi + lo / 2^11 with hi = f16(w), lo = f16((w - hi) * 2^11), same fragment order
+    std::vector<_Float16> stem_l(stem.size()), conv_l(conv.size()), head_l(head.size());
+    auto split = [](float v, _Float16 &hi, _Float16 &lo) {
+        hi = (_Float16)v;
+        lo = (_Float16)((v - (float)hi) * LO_SCALE);
+    };
     for (int s = 0; s < 3; ++s)
         for (int l = 0; l < 64; ++l)
             for (int j = 0; j < 8; ++j) {
                 const int k = 16 * s + 8 * (l >> 5) + j, tap = k >> 2, ch = k & 3, co = l & 31;
                 float v = 0.0f;
                 if (tap < 9 && ch < 3) v = desc->stem_w[((co * 3 + ch) * 3 + tap / 3) * 3 + tap % 3];
-                stem[(s * 64 + l) * 8 + j] = (_Float16)v;
+                split(v, stem[(s * 64 + l) * 8 + j], stem_l[(s * 64 + l) * 8 + j]);
             }
     // ---- 3x3 convs: k-step s: tap = s>>1, cin = (s&1)*16 + 8(l>>5) + j
     for (int L = 0; L < 2 * R; ++L)
@@ -148,14 +170,14 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
                 for (int j = 0; j < 8; ++j) {
                     const int tap = s >> 1, ci = (s & 1) * 16 + 8 * (l >> 5) + j, co = l & 31;
                     const float v = desc->conv_w[((((size_t)L * F + co) * F + ci) * 3 + tap / 3) * 3 + tap % 3];
-                    conv[(((size_t)L * KSTEPS + s) * 64 + l) * 8 + j] = (_Float16)v;
+                    split(v, conv[(((size_t)L * KSTEPS + s) * 64 + l) * 8 + j], conv_l[(((size_t)L * KSTEPS + s) * 64 + l) * 8 + j]);
                 }
     // ---- head 1x1: couts 0..2 (value, policy0, policy1), cin = 16s + 8(l>>5) + j
     for (int s = 0; s < 2; ++s)
         for (int l = 0; l < 64; ++l)
             for (int j = 0; j < 8; ++j) {
                 const int ci = 16 * s + 8 * (l >> 5) + j, co = l & 31;
-                head[(s * 64 + l) * 8 + j] = (_Float16)(co < 3 ? desc->head_w[co * F + ci] : 0.0f);
+                split(co < 3 ? desc->head_w[co * F + ci] : 0.0f, head[(s * 64 + l) * 8 + j], head_l[(s * 64 + l) * 8 + j]);
             }
     std::vector<float> stem_b(desc->stem_b, desc->stem_b + F), conv_b(desc->conv_b, desc->conv_b + (size_t)2 * R * F),
         head_b(4, 0.0f), mlp((size_t)MLP_F4 * 4, 0.0f);
@@ -179,13 +201,14 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
             if (seg == 0) pb[l] = desc->pfc_b[o];
         }
     }
-    if (conv.empty()) conv.resize(8);
+    if (conv.empty()) { conv.resize(8); conv_l.resize(8); }
     if (conv_b.empty()) conv_b.resize(4);
     hipError_t r = hipSuccess;
     const _Float16 *p16;
 #define UP16(vec, field) if (r == hipSuccess) { r = upload(net, vec, &p16); net->d.field = (const half8 *)p16; }
 #define UP32(vec, field) if (r == hipSuccess) r = upload(net, vec, &net->d.field);
     UP16(stem, stem_w) UP16(conv, conv_w) UP16(head, head_w)
+    UP16(stem_l, stem_wl) UP16(conv_l, conv_wl) UP16(head_l, head_wl)
     UP32(stem_b, stem_b) UP32(conv_b, conv_b) UP32(head_b, head_b)
     {
         const float *pm = nullptr;
@@ -203,6 +226,7 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
     net->d.w1 = desc->w1;
     net->d.w2 = desc->w2;
     net->d.n_res = R;
+    net->d.precise = desc->precision == C4_NET_F32X3 ? 1 : 0;
     if (getenv("C4_NET_STAMPS")) {
         void *q = nullptr;
         if (hipMalloc(&q, 8 * 16 * sizeof(unsigned long long)) == hipSuccess) {
@@ -232,6 +256,7 @@ int c4_net_forward(c4_net *net, void *hip_stream, const uint64_t *color0_dev, co
         return C4_EINVAL;
     }
     if (n == 0) return C4_OK;
+    if (net->d.precise) return c4_net_forward_wave(net, hip_stream, color0_dev, color1_dev, n, values_dev, priors_dev);
     const dim3 grid((n + P - 1) / P), block(NTHREADS);
     hipLaunchKernelGGL(c4_net_kernel, grid, block, 0, (hipStream_t)hip_stream, net->d, color0_dev, color1_dev, (int)n,
                        values_dev, priors_dev);
@@ -253,6 +278,16 @@ int c4_net_forward_wave(c4_net *net, void *hip_stream, const uint64_t *color0_de
         return C4_EINVAL;
     }
     if (n == 0) return C4_OK;
+    if (net->d.precise) {
+        hipLaunchKernelGGL(c4_net_wave_precise_kernel, dim3((n + NWAVES - 1) / NWAVES), dim3(NTHREADS), 0, (hipStream_t)hip_stream, net->d,
+                           color0_dev, color1_dev, (int)n, values_dev, priors_dev);
+        hipError_t pr = hipGetLastError();
+        if (pr != hipSuccess) {
+            snprintf(n_err, 512, "c4_net_wave_precise_kernel launch failed: %s", hipGetErrorString(pr));
+            return C4_EDEVICE;
+        }
+        return C4_OK;
+    }
     const int per_block = NWAVES * WP;
     const dim3 grid((n + per_block - 1) / per_block), block(NTHREADS);
     const char *ea = getenv("C4_NET_WAVE_ACTIVE"), *ep = getenv("C4_NET_WAVE_POS");   // timing experiments only

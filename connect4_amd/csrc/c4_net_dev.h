@@ -40,6 +40,9 @@ struct NetDev {
     const float4 *mlp;     // MLP_F4 float4s: value table [11][64][4], policy table [11][64], fc_b[64], vout_w[64], pfc_b[64]
     float vout_b, w1, w2;
     int n_res;
+    // reference-precision mode (C4_NET_F32X3): the scaled low parts of the same weights, same fragment order
+    const half8 *stem_wl, *conv_wl, *head_wl;
+    int precise;
     unsigned long long *stamps;   // diagnostic only (C4_NET_STAMPS=1): [wave][16] s_memtime values of block 0
 };
 
@@ -662,6 +665,293 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
                 if (is_pol) priors[(size_t)go * 7 + lane] = e / sum;
             }
         }
+    }
+    stamp(10);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Reference-precision wave-private forward (C4_NET_F32X3): ONE position per pass.
+// Every fp32 operand x (folded weight, activation) is carried as two fp16 numbers
+//     x  ~=  hi + lo / 2^11,      hi = f16(x),   lo = f16((x - hi) * 2^11)
+// (x - hi is exact in fp32; scaling keeps lo a NORMAL fp16 of x's own magnitude), and a product of two
+// operands as three fp16 MFMAs with fp32 accumulation -- hi*hi into one accumulator, hi*lo + lo*hi into
+// a second one that is folded in with the factor 2^-11 in the epilogue; lo*lo (2^-22 relative) is
+// dropped.  Operand error 2^-22, products exact, sums in fp32: the class of an fp32 convolution whose
+// summation order differs (what the PyTorch-ROCm / MIOpen plan is against the reference's CPU convs).
+// The input planes are 0/1 (exact in fp16), so the stem needs two MFMAs per k-step, every other layer three.
+//   * rows: the position's 42 pixels in two 32-row MFMA tiles; rows 42..63 read the zero row and are never
+//     stored, so a plane needs 43 rows: ping/pong x hi/lo = 4 planes x 3,440 B fit the f16 kernel's two
+//     private buffers (2 x 7,760 B);
+//   * weights: hi and lo fragments stream from L2 through a rolling window of WDEPTH k-steps (the tower's
+//     18 x n_layers k-steps are one linear sequence in memory, so the window rolls across layer boundaries);
+//   * heads and MLPs as in net_forward_wave (fp32 VALU), fed with the folded fp32 activations.
+// ------------------------------------------------------------------------------------------------
+constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
+constexpr int PROWS = PIX + 1;               // 42 real rows + the zero row
+constexpr int PPLANE = PROWS * CS;           // halves per plane (3,440 B)
+constexpr int WDEPTH = 6;                    // k-steps of weights in flight (divides KSTEPS: the window's slot of k-step s is s % 6 in every layer)
+static_assert(4 * PPLANE <= 2 * WACT, "the four planes of the precise forward must fit the wave's two private buffers");
+static_assert(KSTEPS % WDEPTH == 0, "rolling weight window");
+
+__device__ __forceinline__ void split_store(const floatx16 &hi, const floatx16 &lo, _Float16 *dh, _Float16 *dl, int rowoff, int h, bool real)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        half4 oh, ol;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float y = lrelu(hi[4 * q + i] + lo[4 * q + i] * LO_INV);
+            const _Float16 yh = (_Float16)y;
+            oh[i] = yh;
+            ol[i] = (_Float16)((y - (float)yh) * LO_SCALE);
+        }
+        if (real) {
+            *reinterpret_cast<half4 *>(dh + rowoff + 8 * q + 4 * h) = oh;
+            *reinterpret_cast<half4 *>(dl + rowoff + 8 * q + 4 * h) = ol;
+        }
+    }
+}
+
+__device__ __forceinline__ void net_forward_wave_precise(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds,
+                                                         uint64_t b0, uint64_t b1, float *__restrict__ values,
+                                                         float *__restrict__ priors, int out, unsigned long long *stamps = nullptr)
+{
+    int lane_ = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_));     // see net_forward_wave_nt: keep lane-derived addresses out of the caller's loop
+    const int lane = lane_;
+    const int r32 = lane & 31, h = lane >> 5;
+    auto stamp = [&](int i) { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
+    const int n_layers = 2 * nd.n_res;
+    _Float16 *const p0h = buf, *const p0l = buf + PPLANE, *const p1h = buf + 2 * PPLANE, *const p1l = buf + 3 * PPLANE;
+    auto load_bias = [&](const float *b, float4 (&o)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = *reinterpret_cast<const float4 *>(b + 8 * q + 4 * h);
+    };
+    // rolling weight window, primed with the first WDEPTH k-steps of the tower
+    half8 wh[WDEPTH], wl[WDEPTH];
+    const half8 *wph = nd.conv_w + lane, *wpl = nd.conv_wl + lane;
+    const int total_steps = n_layers * KSTEPS;
+#pragma unroll
+    for (int s = 0; s < WDEPTH; ++s) {
+        const int t = s < total_steps ? s : 0;
+        wh[s] = wph[t * 64];
+        wl[s] = wpl[t * 64];
+    }
+    half8 swh[3], swl[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { swh[s] = nd.stem_w[s * 64 + lane]; swl[s] = nd.stem_wl[s * 64 + lane]; }
+    float4 bias[4];
+    load_bias(bias_lds, bias);
+    // input planes (board.py:147-154), 4 halves per row, in plane p1h (the tower writes it only after the stem)
+    _Float16 *inp = p1h;
+    if (lane <= PIX) {
+        half4 v = {};
+        if (lane < PIX) {
+            const int y = lane / 7, x = lane - y * 7;
+            const int bit = x * 7 + (5 - y);
+            v[0] = (_Float16)((__popcll(b0 | b1) & 1) ? 0.0f : 1.0f);
+            v[1] = (_Float16)(float)((b0 >> bit) & 1);
+            v[2] = (_Float16)(float)((b1 >> bit) & 1);
+        }
+        *reinterpret_cast<half4 *>(inp + lane * 4) = v;   // lane == PIX: the zero row of the planes
+    }
+    if (lane < CS) {   // the zero rows of the four planes (the input planes above occupy the first rows of p1h only)
+        p0h[PIX * CS + lane] = (_Float16)0.0f; p0l[PIX * CS + lane] = (_Float16)0.0f;
+        p1h[PIX * CS + lane] = (_Float16)0.0f; p1l[PIX * CS + lane] = (_Float16)0.0f;
+    }
+    // row geometry: tile ti holds rows 32 ti + r32; rows >= 42 read the zero row and store nothing
+    uint32_t rsel2[2][5];
+    int rbase[2];
+    bool real[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int rg = ti * 32 + r32;
+        const int y = rg / 7, x = rg - y * 7;
+        real[ti] = rg < PIX;
+        rbase[ti] = (real[ti] ? rg : PIX) * CS;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) rsel2[ti][j] = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const int ok = -(int)(real[ti] && (unsigned)(y + dy) < 6u && (unsigned)(x + dx) < 7u);
+            const uint32_t off = (uint32_t)((((rg + dy * 7 + dx) & ok) | (PIX & ~ok)) * CS + 8 * h);
+            rsel2[ti][tap >> 1] |= off << (16 * (tap & 1));
+        }
+    }
+    auto rsel = [&](int ti, int tap) -> int { return (int)((rsel2[ti][tap >> 1] >> (16 * (tap & 1))) & 0xffffu); };
+    // ------------------------------------------------------------------ stem: planes -> p0
+    {
+        floatx16 ah[2], al[2];
+        half4 v[2][6];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int rg = ti * 32 + r32;
+            const int y = rg / 7, x = rg - y * 7;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int tap = 4 * (i >> 1) + 2 * h + (i & 1);
+                const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;
+                const int ok = -(int)(real[ti] && tap < 9 && (unsigned)(y + ty - 1) < 6u && (unsigned)(x + tx - 1) < 7u);
+                const int row = ((rg + (ty - 1) * 7 + tx - 1) & ok) | (PIX & ~ok);
+                v[ti][i] = *reinterpret_cast<const half4 *>(inp + row * 4);
+            }
+            ah[ti] = acc_from_bias(bias);
+            al[ti] = floatx16{};
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                half8 bf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bf[j] = v[ti][2 * s][j]; bf[4 + j] = v[ti][2 * s + 1][j]; }
+                ah[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(swh[s], bf, ah[ti], 0, 0, 0);
+                al[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(swl[s], bf, al[ti], 0, 0, 0);
+            }
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) split_store(ah[ti], al[ti], p0h, p0l, rbase[ti], h, real[ti]);
+    }
+    stamp(1);
+    // ------------------------------------------------------------------ residual tower
+    for (int L = 0; L < n_layers; ++L) {
+        const bool second = L & 1;
+        const _Float16 *sh = second ? p1h : p0h, *sl = second ? p1l : p0l;
+        _Float16 *dh = second ? p0h : p1h, *dl = second ? p0l : p1l;
+        floatx16 ah[2], al[2];
+        load_bias(bias_lds + F * (1 + L), bias);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) { ah[ti] = acc_from_bias(bias); al[ti] = floatx16{}; }
+        half8 bh[2], bl[2], nh[2], nl[2];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            bh[ti] = *reinterpret_cast<const half8 *>(sh + rsel(ti, 0));
+            bl[ti] = *reinterpret_cast<const half8 *>(sl + rsel(ti, 0));
+        }
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            if (s + 1 < KSTEPS) {
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti) {
+                    const int o = rsel(ti, (s + 1) >> 1) + ((s + 1) & 1) * 16;
+                    nh[ti] = *reinterpret_cast<const half8 *>(sh + o);
+                    nl[ti] = *reinterpret_cast<const half8 *>(sl + o);
+                }
+            }
+            const half8 cwh = wh[s % WDEPTH], cwl = wl[s % WDEPTH];
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                ah[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh, bh[ti], ah[ti], 0, 0, 0);
+                al[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwl, bh[ti], al[ti], 0, 0, 0);
+                al[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh, bl[ti], al[ti], 0, 0, 0);
+            }
+            {   // refill the window slot just used with k-step (L*18 + s + WDEPTH) of the tower; unconditional
+                // (past the end it re-reads step 0: a branch around the loads would drain vmcnt)
+                int t = L * KSTEPS + s + WDEPTH;
+                t = t < total_steps ? t : 0;
+                wh[s % WDEPTH] = wph[t * 64];
+                wl[s % WDEPTH] = wpl[t * 64];
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) { bh[ti] = nh[ti]; bl[ti] = nl[ti]; }
+        }
+        if (second) {   // + block input (lives in dh/dl): identity MFMAs keep it exact in both accumulators
+            half8 idf[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) idf[s][j] = (_Float16)((16 * s + 8 * h + j) == r32 ? 1.0f : 0.0f);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const half8 xh0 = *reinterpret_cast<const half8 *>(dh + rbase[ti] + 8 * h);
+                const half8 xh1 = *reinterpret_cast<const half8 *>(dh + rbase[ti] + 16 + 8 * h);
+                const half8 xl0 = *reinterpret_cast<const half8 *>(dl + rbase[ti] + 8 * h);
+                const half8 xl1 = *reinterpret_cast<const half8 *>(dl + rbase[ti] + 16 + 8 * h);
+                ah[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[0], xh0, ah[ti], 0, 0, 0);
+                ah[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[1], xh1, ah[ti], 0, 0, 0);
+                al[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[0], xl0, al[ti], 0, 0, 0);
+                al[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[1], xl1, al[ti], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) split_store(ah[ti], al[ti], dh, dl, rbase[ti], h, real[ti]);
+        if (L < 6) stamp(2 + L);
+    }
+    stamp(8);
+    // tower output is in p0 (n_layers is even)
+    // ------------------------------------------------------------------ 1x1 head convs
+    float *hs = reinterpret_cast<float *>(p1h);   // [HSTR] fp32: value plane 0..41, policy planes 42..125 (p1 is free)
+    {
+        const half8 hwh0 = nd.head_w[lane], hwh1 = nd.head_w[64 + lane], hwl0 = nd.head_wl[lane], hwl1 = nd.head_wl[64 + lane];
+        const float hb0 = nd.head_b[0], hb1 = nd.head_b[1], hb2 = nd.head_b[2];
+        float o0[2], o1[2], o2[2];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const half8 xh0 = *reinterpret_cast<const half8 *>(p0h + rbase[ti] + 8 * h);
+            const half8 xh1 = *reinterpret_cast<const half8 *>(p0h + rbase[ti] + 16 + 8 * h);
+            const half8 xl0 = *reinterpret_cast<const half8 *>(p0l + rbase[ti] + 8 * h);
+            const half8 xl1 = *reinterpret_cast<const half8 *>(p0l + rbase[ti] + 16 + 8 * h);
+            floatx16 a = {}, b = {};
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwh0, xh0, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwh1, xh1, a, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwl0, xh0, b, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwl1, xh1, b, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwh0, xl0, b, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwh1, xl1, b, 0, 0, 0);
+            o0[ti] = lrelu(a[0] + b[0] * LO_INV + hb0);
+            o1[ti] = lrelu(a[1] + b[1] * LO_INV + hb1);
+            o2[ti] = lrelu(a[2] + b[2] * LO_INV + hb2);
+        }
+        // every lane has read the tower output and p1 is dead: the head planes may overwrite p1h
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int rg = ti * 32 + r32;
+            if (h == 0 && rg < PIX) {
+                hs[0 * PIX + rg] = o0[ti];
+                hs[1 * PIX + rg] = o1[ti];
+                hs[2 * PIX + rg] = o2[ti];
+            }
+        }
+        if (lane < 2) hs[HEADV + lane] = 0.0f;   // pad 126,127
+    }
+    stamp(9);
+    // ------------------------------------------------------------------ MLP heads (fp32 VALU), as in net_forward_wave
+    {
+        const float *vt_b = reinterpret_cast<const float *>(mlp + VT_F4 + PT_F / 4);   // fc_b | vout_w | pfc_b
+        const float *pt = reinterpret_cast<const float *>(mlp + VT_F4);
+        const float4 *hA4 = reinterpret_cast<const float4 *>(hs);
+        float v0 = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 11; ++g) {
+            const float4 wv = mlp[g * 64 + lane];
+            const float4 xa = hA4[g];
+            v0 += wv.x * xa.x + wv.y * xa.y + wv.z * xa.z + wv.w * xa.w;
+        }
+        const int seg = lane >> 3;
+        const float *hpA = hs + PIX + seg * 11;
+        float l0 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 11; ++c) {
+            const float wv = pt[c * 64 + lane];      // zero where seg*11 + c >= 84 or (lane & 7) == 7
+            const int cc = seg * 11 + c < 2 * PIX ? c : 2 * PIX - 1 - seg * 11;
+            l0 += wv * hpA[cc];
+        }
+        l0 += dppf<0x128>(l0);
+#pragma unroll
+        for (int m = 16; m <= 32; m <<= 1) l0 += __shfl_xor(l0, m, 64);
+        const float fb = vt_b[lane], vw = vt_b[64 + lane], pb = vt_b[128 + lane];
+        const bool is_pol = lane < 7;
+        const float a = v0 + fb;
+        const float lg = l0 + pb;
+        const float rs = sum16(lane < PIX ? vw * lrelu(a) : 0.0f);               // model.py:83-85
+        const float vsum = readlane_f(rs, 0) + readlane_f(rs, 16) + readlane_f(rs, 32);
+        const float value = (tanhf(vsum + nd.vout_b) + nd.w1) * nd.w2;           // model.py:86-88
+        const float mx = max8(is_pol ? lg : -INFINITY);
+        const float e = is_pol ? expf(lg - mx) : 0.0f;
+        const float sum = sum8(e);
+        if (lane == 0) values[out] = value;
+        if (is_pol) priors[(size_t)out * 7 + lane] = e / sum;
     }
     stamp(10);
 }

@@ -29,7 +29,9 @@ def _host_eval(evaluator, board):
 
 
 class _Searcher:
-    """Owns one stop-after-move engine per (mode, batch size) and drives it."""
+    """Owns ONE stop-after-move engine per evaluator mode, sized for the largest batch seen; smaller batches
+    run on its first n slots (c4_reset parks the rest), so a match whose live-board count shrinks every ply
+    keeps a single node pool instead of one per batch size."""
 
     def __init__(self, config: MCTSConfig, evaluator, device=0):
         self.config = config
@@ -46,11 +48,13 @@ class _Searcher:
             self.kind = "host"
 
     def _engine(self, mode, n):
-        key = (mode, n)
-        if key not in self._engines:
-            self._engines[key] = Engine(n, eval_mode=mode, rng_mode=L.RNG_TAPE, stop_after_move=True,
-                                        device=self.device, **self.config.engine_kwargs())
-        return self._engines[key]
+        eng = self._engines.get(mode)
+        if eng is None or eng.n_slots < n:
+            if eng is not None:
+                eng.close()
+            eng = self._engines[mode] = Engine(n, eval_mode=mode, rng_mode=L.RNG_TAPE, stop_after_move=True,
+                                               device=self.device, **self.config.engine_kwargs())
+        return eng
 
     def close(self):
         for e in self._engines.values():
@@ -95,7 +99,7 @@ class _Searcher:
             eng.set_tapes(*self._tapes(boards, pick))
             eng.reset(c0, c1)
             self._drive_host(eng, np.float32 if f32 else np.float64)
-        return eng.read_roots()
+        return list(eng.read_roots()[:n])
 
     def _drive_device(self, eng):
         import torch

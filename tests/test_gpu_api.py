@@ -229,12 +229,12 @@ def test_end_to_end_net_driven_search_matches_reference():
     """The whole hot path on the GPU -- HIP tree walk + the policy/value net -- against the reference's
     NN-driven searches with data/example_net.pth (tests/golden/search_net.json, captured from the
     unmodified reference on CPU).
-      * fp32 PyTorch-ROCm net: conv outputs differ from the CPU's by ~1e-6, far below the score gaps
-        that decide an argmax in these positions -> visit counts must be IDENTICAL, root value sums
-        within 1e-4;
-      * fused fp16-storage MFMA net: outputs differ by up to 5e-3, so individual visit counts may
-        move; stated tolerance: the visit distribution stays within 0.08 total variation and the
-        chosen move is the same."""
+      * fp32 PyTorch-ROCm net and the fused MFMA net in its reference-precision mode (fp16 hi+lo split,
+        fp32 accumulation): outputs differ from the CPU's by ~1e-6, far below the score gaps that decide an
+        argmax in these positions -> visit counts must be IDENTICAL, root value sums within 1e-4;
+      * fused net in fp16-storage mode (the fast default): outputs differ by up to 5e-3, so individual
+        visit counts may move; stated tolerance: the visit distribution stays within 0.08 total variation
+        and the chosen move is the same."""
     import torch
     from connect4_amd.board import Board
     from connect4_amd.evaluators import DeviceNetEvaluator
@@ -243,10 +243,11 @@ def test_end_to_end_net_driven_search_matches_reference():
     from connect4_amd.net import InferenceNet
     z = load_npz("net_golden.npz")
     sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w__")}
-    nets = {"fp32": InferenceNet(sd, device="cuda", dtype=torch.float32), "fused": FusedNet(sd)}
+    nets = {"fp32": InferenceNet(sd, device="cuda", dtype=torch.float32), "fused_f32x3": FusedNet(sd, precision="f32x3"),
+            "fused_f16": FusedNet(sd)}
     cases = [c for c in load_json("search_net.json") if c["noise"] is None]
     assert len(cases) >= 7
-    exact = 0
+    exact = {"fp32": 0, "fused_f32x3": 0}
     for case in cases:
         board = Board.from_bits(case["board"]["c0"], case["board"]["c1"])
         ref_n = np.array(case["N"], dtype=np.float64)
@@ -255,15 +256,47 @@ def test_end_to_end_net_driven_search_matches_reference():
             got = np.zeros(7)
             for c in tree.root.children:
                 got[c.name] = c.data.search_value.visit_count if c.data.search_value else 0
-            if name == "fp32":
-                assert got.tolist() == ref_n.tolist(), (case["name"], got, ref_n)
+            if name in exact:
+                assert got.tolist() == ref_n.tolist(), (name, case["name"], got, ref_n)
                 assert abs(tree.root.data.search_value.value_sum - case["root_W"]) < 1e-4 * case["root_N"]
-                exact += 1
+                exact[name] += 1
             else:
                 tv = 0.5 * np.abs(got / got.sum() - ref_n / ref_n.sum()).sum()
                 assert tv < 0.08, (case["name"], got, ref_n, tv)
                 assert tree.best_move().name == case["best_move"], case["name"]
-    assert exact == len(cases)
+    assert exact == {"fp32": len(cases), "fused_f32x3": len(cases)}
+
+
+def test_precise_fused_selfplay_equals_separate_kernels(oracle):
+    """The reference-precision net inside the wave-autonomous self-play kernel plays exactly the games that
+    alternating c4_step / c4_net_forward launches play, and they replay on the oracle from the device's cache."""
+    from connect4_amd import _lib as L
+    from connect4_amd.config import MCTSConfig
+    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.net import random_init_state_dict
+    from connect4_amd.selfplay import SelfPlay
+    from oracle.replay import oracle_config, random_tapes, replay_game
+    net = FusedNet(random_init_state_dict(seed=0), precision="f32x3")
+    cfg = MCTSConfig.self_play(40)
+    noise, u = random_tapes(80, cfg.root_dirichlet_alpha, seed=8)
+    out = []
+    for fused in (False, True):
+        sp = SelfPlay(net, 40, cfg, seed=2, games_target=80, record_capacity_games=80, use_graph=False, fused_loop=fused,
+                      steps_per_launch=16, max_inner_iters=3, rng_mode=L.RNG_TAPE)
+        sp.engine.set_tapes(noise, u)
+        sp.engine.reset()
+        for _ in range(400):
+            sp.run_steps(64)
+            if sp.stats()["active_slots"] == 0:
+                break
+        recs = sp.engine.drain_games()
+        assert len(recs) == 80 and sp.stats()["bad_evals"] == 0
+        if fused:
+            for r in recs[:6]:
+                replay_game(oracle_config(cfg), sp.engine, net, r, noise[r.game_id], u[r.game_id])
+        out.append([(r.game_id, list(r.move[:r.length]), r.result, list(r.value[:r.length])) for r in recs])
+        sp.close()
+    assert out[0] == out[1]
 
 
 def test_wide_net_falls_back_to_pytorch_plan():

@@ -70,3 +70,38 @@ def test_wave_private_forward_is_bit_identical(oracle, n):
         v, p = net.evaluate_bits(c0, c1)
         wv, wp = net.evaluate_bits(c0, c1, wave=True)
         assert np.array_equal(v, wv) and np.array_equal(p, wp)
+
+
+# ---------------------------------------------------------------- reference-precision mode (C4_NET_F32X3)
+def test_precise_net_vs_reference_golden():
+    """fp16 hi+lo split, three MFMAs per k-step, fp32 accumulation: the reference's own fp32 outputs on
+    example_net.pth (tests/golden/net_golden.npz, written by the unmodified reference on CPU) within 5e-5."""
+    from connect4_amd.fused_net import FusedNet
+    z = load_npz("net_golden.npz")
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w__")}
+    net = FusedNet(sd, precision="f32x3")
+    v, p = net.evaluate_bits(z["in_c0"], z["in_c1"])
+    dv, dp = np.abs(v - z["out_values"]).max(), np.abs(p - z["out_priors"]).max()
+    print("precise fused vs reference golden: max |dv| %.3g  max |dp| %.3g" % (dv, dp))
+    assert dv <= 5e-5 and dp <= 5e-5
+    np.testing.assert_allclose(p.sum(1), 1.0, atol=1e-5)
+    wv, wp = net.evaluate_bits(z["in_c0"], z["in_c1"], wave=True)       # both entry points: one implementation
+    assert np.array_equal(v, wv) and np.array_equal(p, wp)
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 4099])
+def test_precise_net_vs_pytorch_fp32(oracle, n):
+    """... and the fp32 PyTorch-ROCm plan of a random-init net on random positions (incl. ragged last
+    workgroups and a second tower depth) within 2e-5."""
+    from connect4_amd.engine import board_planes
+    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.net import InferenceNet, NetConfig, random_init_state_dict
+    for n_res in (3, 1):
+        sd = random_init_state_dict(NetConfig(n_residuals=n_res), seed=n_res)
+        c0, c1 = random_positions(oracle, n, seed=n)
+        ref = InferenceNet(sd, device="cuda", dtype=torch.float32)
+        rv, rp = ref(torch.from_numpy(board_planes(c0, c1)).cuda())
+        v, p = FusedNet(sd, precision="f32x3").evaluate_bits(c0, c1)
+        dv, dp = np.abs(v - rv.cpu().numpy()).max(), np.abs(p - rp.cpu().numpy()).max()
+        print("n=%d n_res=%d precise vs torch fp32: max |dv| %.3g  max |dp| %.3g" % (n, n_res, dv, dp))
+        assert dv < 2e-5 and dp < 2e-5

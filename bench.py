@@ -39,7 +39,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 FP32_MATRIX_PEAK_TF = 157.3  # fp32-in MFMA / vector peak
 F16_MFMA_PEAK_TF = 2500.0    # dense
-NET_MFLOP_PER_POSITION = 4.74  # BASELINE.md section 4 (32 filters, 3 residual blocks)
+
+
+def net_mflop_per_position(filters=32, residuals=3):
+    """4.74 MFLOP for 32 filters / 3 residual blocks (stem + tower + 1x1 heads + MLPs)."""
+    macs = 42 * 9 * 3 * filters + 2 * residuals * 42 * 9 * filters * filters + 42 * filters * 3 + 42 * 42 + 42 + 84 * 7
+    return 2.0 * macs / 1e6
+
+
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
@@ -55,6 +62,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5, help="untimed steps after the pre-roll")
     ap.add_argument("--slots", type=int, default=4096, help="parallel games per GPU")
     ap.add_argument("--sims", type=int, default=800)
+    ap.add_argument("--filters", type=int, default=32, help="net width (32 = the reference's default / BASELINE config; 64 = its example_config)")
+    ap.add_argument("--residuals", type=int, default=3)
+    ap.add_argument("--fc-layers", type=int, default=4)
     ap.add_argument("--quanta-per-step", type=int, default=256,
                     help="time quanta (rollout steps) per bench step = per launch of the fused kernel")
     ap.add_argument("--preroll-games-per-slot", type=float, default=4.0,
@@ -276,7 +286,8 @@ def run_rank(args):
         args.net_dtype = "f16" if args.net_precision == "f16" else "f32"
     elif args.net_dtype is None:
         args.net_dtype = "f32"
-    sd = random_init_state_dict(NetConfig(), seed=0)
+    sd = random_init_state_dict(NetConfig(filters=args.filters, n_residuals=args.residuals, n_fc_layers=args.fc_layers), seed=0)
+    args.net_mflop = net_mflop_per_position(args.filters, args.residuals)
     sp, net = make_selfplay(args, sd, rank, local_rank, args.net_precision)
 
     def barrier():
@@ -339,10 +350,10 @@ def run_rank(args):
             "collective_backend": (backend if world > 1 else None),
             "config": {
                 "workload": "%d parallel self-play games per GPU, %d sims/move, random-init resnet "
-                            "(32 filters, 3 residual blocks), %dxMI355X" % (args.slots, args.sims, world),
+                            "(%d filters, %d residual blocks), %dxMI355X" % (args.slots, args.sims, args.filters, args.residuals, world),
                 "step": "one launch of the persistent self-play kernel = %d quanta of %d shader cycles for every game"
                         % (args.quanta_per_step, args.time_budget),
-                "slots_per_gpu": args.slots, "simulations": args.sims, "net": "32f-3res-4fc",
+                "slots_per_gpu": args.slots, "simulations": args.sims, "net": "%df-%dres-%dfc" % (args.filters, args.residuals, args.fc_layers),
                 "net_impl": args.net, "net_precision": (args.net_precision if args.net == "fused" else args.net_dtype),
                 "tree_dtype": "u64 bitboards, u32 visits, f64 value sums/priors",
                 "parallelism": "games sharded over %d GPU(s), no collective in the rollout path" % world,
@@ -369,7 +380,7 @@ def run_rank(args):
             r_depth = delta["depth_sum"] / max(1, delta["simulations"])
             tree_b = tree_bytes_per_sim(r_depth) * r_sims
             ach = tree_b / (launch_ms * 1e-3) / 1e9
-            mfma_tf = NET_MFLOP_PER_POSITION * 1e6 * r_evals / (launch_ms * 1e-3) / 1e12
+            mfma_tf = args.net_mflop * 1e6 * r_evals / (launch_ms * 1e-3) / 1e12
             # PMC traffic only from a record of launches of exactly this shape
             pmc_ok = (pmc.get("kernel", "") == "c4_selfplay_wave_kernel" and args.slots == pmc.get("slots") and args.sims == pmc.get("sims")
                       and args.max_inner == pmc.get("max_inner") and args.quanta_per_step == pmc.get("quanta_per_launch")
@@ -386,7 +397,7 @@ def run_rank(args):
                 "mfma_frac_of_dense_f16_peak": mfma_tf / F16_MFMA_PEAK_TF,
                 "note": "tree walk = dependent-load (latency) bound pointer chase, bytes = (136*D+332) per simulation (node records, "
                         "path, cache line); the network part of the same kernel is counted in mfma_achieved_tflops "
-                        "(4.74 MFLOP per evaluated leaf); duration = HIP events around the timed region / launches",
+                        "(%.2f MFLOP per evaluated leaf); duration = HIP events around the timed region / launches" % args.net_mflop,
             }
         if prof:
             out.update(secondary_rooflines(prof, args, pmc))
@@ -509,7 +520,7 @@ def secondary_rooflines(prof, args, pmc):
         "algorithmic_bytes_per_launch": prof["tree_bytes_per_launch"],
         "note": "dependent-load (latency) bound pointer chase; bytes = (136*D+332) per simulation",
     }
-    tf = NET_MFLOP_PER_POSITION * 1e6 * args.slots / (prof["net_ms"] * 1e-3) / 1e12
+    tf = args.net_mflop * 1e6 * args.slots / (prof["net_ms"] * 1e-3) / 1e12
     peak = FP32_MATRIX_PEAK_TF if (args.net != "fused" and args.net_dtype == "f32") else F16_MFMA_PEAK_TF
     netr = {
         "kernel": ("c4_net_kernel (fused stem+tower+heads, v_mfma_f32_32x32x16_f16, precision %s)" % args.net_precision if args.net == "fused"

@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
 // bit-identical to net_forward_block's).
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(4))) const Dev const_dev;
-template <int TS, bool PRECISE>
+template <int TS, int MODE>
 __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const Dev *d_dev, c4net::NetDev nd, float *__restrict__ values,
                                                                            float *__restrict__ priors, int n_steps)
 {
@@ -1271,10 +1271,10 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
             const int has = __builtin_amdgcn_readfirstlane(smem[sq].has_leaf() ? 1 : 0);
             if (has) pend_slot[cnt++] = sq;
         }
-        if (PRECISE) {   // reference-precision net (C4_NET_F32X3): one position per pass
+        if (MODE != NETMODE_F32_2POS) {   // reference-precision net or 64 filters: one position per pass
             for (int i = 0; i < cnt; ++i) {
                 const int sa = pend_slot[i];
-                net_forward_wave_precise(nd, &act[wv][0][0], mlp, s_bias, smem[sa].leaf0, smem[sa].leaf1, s_val, s_pri, sa);
+                net_forward_wave1_mode<MODE>(nd, &act[wv][0][0], mlp, s_bias, smem[sa].leaf0, smem[sa].leaf1, s_val, s_pri, sa);
             }
         } else {
             for (int i = 0; i < cnt; i += WP) {
@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
             }
         }
         lds_fence();   // answers (LDS) before the next tree_step reads them
-        if (d.has_stamps) { t_tree += tb - ta; t_net += __builtin_amdgcn_s_memtime() - tb; n_pass += PRECISE ? cnt : (cnt + WP - 1) / WP; }
+        if (d.has_stamps) { t_tree += tb - ta; t_net += __builtin_amdgcn_s_memtime() - tb; n_pass += MODE != NETMODE_F32_2POS ? cnt : (cnt + WP - 1) / WP; }
     }
     if (d.has_stamps && blockIdx.x < 128 && (threadIdx.x & 63) == 0) {   // per wave: tree cycles, net cycles | passes << 48
         d.cold->stamps[blockIdx.x * 16 + wv] = t_tree;
@@ -1946,15 +1946,17 @@ int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *prior
             e->d_uploaded = e->d;
         }
         const dim3 g32((e->d.G + 31) / 32), g16((e->d.G + 15) / 16), blk(c4net::NTHREADS);
-        if (nd.precise) {
-            if (e->fused_slots == 32) hipLaunchKernelGGL((c4_selfplay_wave_kernel<32, true>), g32, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps);
-            else hipLaunchKernelGGL((c4_selfplay_wave_kernel<16, true>), g16, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps);
-        } else if (e->fused_slots == 32)
-            hipLaunchKernelGGL((c4_selfplay_wave_kernel<32, false>), g32, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps);
-        else
-            hipLaunchKernelGGL((c4_selfplay_wave_kernel<16, false>), g16, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps);
-    } else if (nd.precise) {
-        set_err(e->err, "C4_FUSED_MODE=block has no reference-precision forward; use the default wave-autonomous kernel");
+#define C4_LAUNCH_WAVE(MODE)                                                                                                       \
+    do {                                                                                                                           \
+        if (e->fused_slots == 32) hipLaunchKernelGGL((c4_selfplay_wave_kernel<32, MODE>), g32, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps); \
+        else hipLaunchKernelGGL((c4_selfplay_wave_kernel<16, MODE>), g16, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps); \
+    } while (0)
+        if (nd.mode == c4net::NETMODE_F64) C4_LAUNCH_WAVE(c4net::NETMODE_F64);
+        else if (nd.mode == c4net::NETMODE_F32_PRECISE) C4_LAUNCH_WAVE(c4net::NETMODE_F32_PRECISE);
+        else C4_LAUNCH_WAVE(c4net::NETMODE_F32_2POS);
+#undef C4_LAUNCH_WAVE
+    } else if (nd.mode != c4net::NETMODE_F32_2POS) {
+        set_err(e->err, "C4_FUSED_MODE=block serves only the 32-filter fp16 net; use the default wave-autonomous kernel");
         return C4_ESTATE;
     } else if (e->fused_slots == 32)
         hipLaunchKernelGGL(c4_selfplay_kernel<32>, dim3((e->d.G + 31) / 32), dim3(c4net::NTHREADS), 0, st, e->d, nd, values_dev, priors_dev, (int)n_steps);

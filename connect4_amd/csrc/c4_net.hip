@@ -75,12 +75,13 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_wave_kernel(NetDev nd, const 
                      values, priors, pA, pB, (nd.stamps && blockIdx.x == 0) ? nd.stamps + wv * 16 : nullptr);
 }
 
-// Reference-precision forward (C4_NET_F32X3, net_forward_wave_precise): one position per wave.  Both
-// c4_net_forward and c4_net_forward_wave run this kernel for a precise net (one implementation, so the two
-// entry points and the fused self-play kernel cannot disagree).
-__global__ __launch_bounds__(NTHREADS) void c4_net_wave_precise_kernel(NetDev nd, const uint64_t *__restrict__ c0,
-                                                                       const uint64_t *__restrict__ c1, int n,
-                                                                       float *__restrict__ values, float *__restrict__ priors)
+// One-position wave-private forward (net_forward_wave1: reference precision at 32 filters, fp16 at 64 filters): one
+// position per wave.  Both c4_net_forward and c4_net_forward_wave run this kernel for such a net (one
+// implementation, so the two entry points and the fused self-play kernel cannot disagree).
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS) void c4_net_wave1_kernel(NetDev nd, const uint64_t *__restrict__ c0,
+                                                                const uint64_t *__restrict__ c1, int n,
+                                                                float *__restrict__ values, float *__restrict__ priors)
 {
     __shared__ __attribute__((aligned(16))) _Float16 act[NWAVES][2][WACT];
     __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
@@ -91,8 +92,8 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_wave_precise_kernel(NetDev nd
     const int wv = threadIdx.x >> 6;
     const int p = blockIdx.x * NWAVES + wv;
     if (p >= n) return;
-    net_forward_wave_precise(nd, &act[wv][0][0], mlp, s_bias, c0[p], c1[p], values, priors, p,
-                             (nd.stamps && blockIdx.x == 0) ? nd.stamps + wv * 16 : nullptr);
+    net_forward_wave1_mode<MODE>(nd, &act[wv][0][0], mlp, s_bias, c0[p], c1[p], values, priors, p,
+                                 (nd.stamps && blockIdx.x == 0) ? nd.stamps + wv * 16 : nullptr);
 }
 
 thread_local char n_err[512] = "";
@@ -129,13 +130,20 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
 {
     if (!desc || !out) { snprintf(n_err, 512, "c4_net_create: null argument"); return C4_EINVAL; }
     *out = nullptr;
-    if (desc->filters != F || desc->channels != 3 || desc->n_residuals < 0 || desc->n_residuals > 64) {
-        snprintf(n_err, 512, "fused net supports channels=3, filters=%d (got channels=%d filters=%d residuals=%d)",
-                 F, desc->channels, desc->filters, desc->n_residuals);
+    const int FW = desc->filters;
+    if ((FW != 32 && FW != 64) || desc->channels != 3 || desc->n_residuals < 0 ||
+        FW * (1 + 2 * desc->n_residuals) > BIAS_LDS_FLOATS) {
+        snprintf(n_err, 512, "fused net supports channels=3, filters 32 (<= 64 residual blocks) or 64 (<= 32) "
+                 "(got channels=%d filters=%d residuals=%d)", desc->channels, desc->filters, desc->n_residuals);
         return C4_EINVAL;
     }
     if (desc->precision != C4_NET_F16 && desc->precision != C4_NET_F32X3) {
         snprintf(n_err, 512, "c4_net_create: unknown precision %d", desc->precision);
+        return C4_EINVAL;
+    }
+    if (!wave1_supported(FW, desc->precision == C4_NET_F32X3)) {
+        snprintf(n_err, 512, "c4_net_create: the reference-precision forward is offered for 32 filters only "
+                 "(the hi/lo planes of %d filters do not fit a wave's private LDS)", FW);
         return C4_EINVAL;
     }
     int ndev = 0;
@@ -147,8 +155,11 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
     net->device = device;
     memset(&net->d, 0, sizeof(NetDev));
     const int R = desc->n_residuals;
-    // ---- stem: A[cout][k], k = tap*4 + ch (ch 3 zero), 48 = 3 k-steps; lane l holds cout l&31, k = 16s + 8(l>>5) + j
-    std::vector<_Float16> stem(3 * 64 * 8), conv((size_t)2 * R * KSTEPS * 64 * 8), head(2 * 64 * 8);
+    const int CB = FW / 32, KPT = FW / 16, KS = 9 * KPT;   // cout blocks, k-steps per tap, k-steps per layer
+    // A fragments in MFMA lane order: fragment (k-step s, cout block cb) at [(s * CB + cb) * 64 + lane][8]; lane l
+    // holds cout 32 cb + (l & 31) and the 8 k's 16 s + 8 (l >> 5) + j.
+    // ---- stem: k = tap*4 + ch (ch 3 zero), 48 = 3 k-steps
+    std::vector<_Float16> stem((size_t)3 * CB * 64 * 8), conv((size_t)2 * R * KS * CB * 64 * 8), head((size_t)KPT * 64 * 8);
     // reference-precision mode: w ~= hi + lo / 2^11 with hi = f16(w), lo = f16((w - hi) * 2^11), same fragment order
     std::vector<_Float16> stem_l(stem.size()), conv_l(conv.size()), head_l(head.size());
     auto split = [](float v, _Float16 &hi, _Float16 &lo) {
@@ -156,30 +167,34 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
         lo = (_Float16)((v - (float)hi) * LO_SCALE);
     };
     for (int s = 0; s < 3; ++s)
-        for (int l = 0; l < 64; ++l)
-            for (int j = 0; j < 8; ++j) {
-                const int k = 16 * s + 8 * (l >> 5) + j, tap = k >> 2, ch = k & 3, co = l & 31;
-                float v = 0.0f;
-                if (tap < 9 && ch < 3) v = desc->stem_w[((co * 3 + ch) * 3 + tap / 3) * 3 + tap % 3];
-                split(v, stem[(s * 64 + l) * 8 + j], stem_l[(s * 64 + l) * 8 + j]);
-            }
-    // ---- 3x3 convs: k-step s: tap = s>>1, cin = (s&1)*16 + 8(l>>5) + j
-    for (int L = 0; L < 2 * R; ++L)
-        for (int s = 0; s < KSTEPS; ++s)
+        for (int cb = 0; cb < CB; ++cb)
             for (int l = 0; l < 64; ++l)
                 for (int j = 0; j < 8; ++j) {
-                    const int tap = s >> 1, ci = (s & 1) * 16 + 8 * (l >> 5) + j, co = l & 31;
-                    const float v = desc->conv_w[((((size_t)L * F + co) * F + ci) * 3 + tap / 3) * 3 + tap % 3];
-                    split(v, conv[(((size_t)L * KSTEPS + s) * 64 + l) * 8 + j], conv_l[(((size_t)L * KSTEPS + s) * 64 + l) * 8 + j]);
+                    const int k = 16 * s + 8 * (l >> 5) + j, tap = k >> 2, ch = k & 3, co = 32 * cb + (l & 31);
+                    float v = 0.0f;
+                    if (tap < 9 && ch < 3) v = desc->stem_w[((co * 3 + ch) * 3 + tap / 3) * 3 + tap % 3];
+                    const size_t at = (((size_t)s * CB + cb) * 64 + l) * 8 + j;
+                    split(v, stem[at], stem_l[at]);
                 }
+    // ---- 3x3 convs: k-step s: tap = s / KPT, cin = (s % KPT)*16 + 8(l>>5) + j
+    for (int L = 0; L < 2 * R; ++L)
+        for (int s = 0; s < KS; ++s)
+            for (int cb = 0; cb < CB; ++cb)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int tap = s / KPT, ci = (s % KPT) * 16 + 8 * (l >> 5) + j, co = 32 * cb + (l & 31);
+                        const float v = desc->conv_w[((((size_t)L * FW + co) * FW + ci) * 3 + tap / 3) * 3 + tap % 3];
+                        const size_t at = ((((size_t)L * KS + s) * CB + cb) * 64 + l) * 8 + j;
+                        split(v, conv[at], conv_l[at]);
+                    }
     // ---- head 1x1: couts 0..2 (value, policy0, policy1), cin = 16s + 8(l>>5) + j
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < KPT; ++s)
         for (int l = 0; l < 64; ++l)
             for (int j = 0; j < 8; ++j) {
                 const int ci = 16 * s + 8 * (l >> 5) + j, co = l & 31;
-                split(co < 3 ? desc->head_w[co * F + ci] : 0.0f, head[(s * 64 + l) * 8 + j], head_l[(s * 64 + l) * 8 + j]);
+                split(co < 3 ? desc->head_w[co * FW + ci] : 0.0f, head[((size_t)s * 64 + l) * 8 + j], head_l[((size_t)s * 64 + l) * 8 + j]);
             }
-    std::vector<float> stem_b(desc->stem_b, desc->stem_b + F), conv_b(desc->conv_b, desc->conv_b + (size_t)2 * R * F),
+    std::vector<float> stem_b(desc->stem_b, desc->stem_b + FW), conv_b(desc->conv_b, desc->conv_b + (size_t)2 * R * FW),
         head_b(4, 0.0f), mlp((size_t)MLP_F4 * 4, 0.0f);
     for (int i = 0; i < 3; ++i) head_b[i] = desc->head_b[i];
     {
@@ -227,6 +242,8 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
     net->d.w2 = desc->w2;
     net->d.n_res = R;
     net->d.precise = desc->precision == C4_NET_F32X3 ? 1 : 0;
+    net->d.filters = FW;
+    net->d.mode = FW == 64 ? NETMODE_F64 : (net->d.precise ? NETMODE_F32_PRECISE : NETMODE_F32_2POS);
     if (getenv("C4_NET_STAMPS")) {
         void *q = nullptr;
         if (hipMalloc(&q, 8 * 16 * sizeof(unsigned long long)) == hipSuccess) {
@@ -256,7 +273,7 @@ int c4_net_forward(c4_net *net, void *hip_stream, const uint64_t *color0_dev, co
         return C4_EINVAL;
     }
     if (n == 0) return C4_OK;
-    if (net->d.precise) return c4_net_forward_wave(net, hip_stream, color0_dev, color1_dev, n, values_dev, priors_dev);
+    if (net->d.mode != NETMODE_F32_2POS) return c4_net_forward_wave(net, hip_stream, color0_dev, color1_dev, n, values_dev, priors_dev);
     const dim3 grid((n + P - 1) / P), block(NTHREADS);
     hipLaunchKernelGGL(c4_net_kernel, grid, block, 0, (hipStream_t)hip_stream, net->d, color0_dev, color1_dev, (int)n,
                        values_dev, priors_dev);
@@ -278,12 +295,15 @@ int c4_net_forward_wave(c4_net *net, void *hip_stream, const uint64_t *color0_de
         return C4_EINVAL;
     }
     if (n == 0) return C4_OK;
-    if (net->d.precise) {
-        hipLaunchKernelGGL(c4_net_wave_precise_kernel, dim3((n + NWAVES - 1) / NWAVES), dim3(NTHREADS), 0, (hipStream_t)hip_stream, net->d,
-                           color0_dev, color1_dev, (int)n, values_dev, priors_dev);
+    if (net->d.mode != NETMODE_F32_2POS) {
+        const dim3 g1((n + NWAVES - 1) / NWAVES), b1(NTHREADS);
+        if (net->d.mode == NETMODE_F64)
+            hipLaunchKernelGGL(c4_net_wave1_kernel<NETMODE_F64>, g1, b1, 0, (hipStream_t)hip_stream, net->d, color0_dev, color1_dev, (int)n, values_dev, priors_dev);
+        else
+            hipLaunchKernelGGL(c4_net_wave1_kernel<NETMODE_F32_PRECISE>, g1, b1, 0, (hipStream_t)hip_stream, net->d, color0_dev, color1_dev, (int)n, values_dev, priors_dev);
         hipError_t pr = hipGetLastError();
         if (pr != hipSuccess) {
-            snprintf(n_err, 512, "c4_net_wave_precise_kernel launch failed: %s", hipGetErrorString(pr));
+            snprintf(n_err, 512, "c4_net_wave1_kernel launch failed: %s", hipGetErrorString(pr));
             return C4_EDEVICE;
         }
         return C4_OK;

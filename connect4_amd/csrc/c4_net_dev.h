@@ -43,6 +43,8 @@ struct NetDev {
     // reference-precision mode (C4_NET_F32X3): the scaled low parts of the same weights, same fragment order
     const half8 *stem_wl, *conv_wl, *head_wl;
     int precise;
+    int filters;           // 32 or 64
+    int mode;              // NETMODE_* the kernels are specialised for
     unsigned long long *stamps;   // diagnostic only (C4_NET_STAMPS=1): [wave][16] s_memtime values of block 0
 };
 
@@ -670,8 +672,12 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
 }
 
 // ------------------------------------------------------------------------------------------------
-// Reference-precision wave-private forward (C4_NET_F32X3): ONE position per pass.
-// Every fp32 operand x (folded weight, activation) is carried as two fp16 numbers
+// One-position wave-private forward, net_forward_wave1<FW, PRECISE>: the general form of the wave-private
+// forward -- any supported width FW (32 or 64 filters = 1 or 2 cout blocks of 32 per MFMA), optionally in
+// reference precision -- for ONE position per pass.  (net_forward_wave above is the tuned special case
+// FW = 32, fp16 storage, two positions per pass.)
+//
+// PRECISE (C4_NET_F32X3): every fp32 operand x (folded weight, activation) is carried as two fp16 numbers
 //     x  ~=  hi + lo / 2^11,      hi = f16(x),   lo = f16((x - hi) * 2^11)
 // (x - hi is exact in fp32; scaling keeps lo a NORMAL fp16 of x's own magnitude), and a product of two
 // operands as three fp16 MFMAs with fp32 accumulation -- hi*hi into one accumulator, hi*lo + lo*hi into
@@ -680,42 +686,56 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
 // summation order differs (what the PyTorch-ROCm / MIOpen plan is against the reference's CPU convs).
 // The input planes are 0/1 (exact in fp16), so the stem needs two MFMAs per k-step, every other layer three.
 //   * rows: the position's 42 pixels in two 32-row MFMA tiles; rows 42..63 read the zero row and are never
-//     stored, so a plane needs 43 rows: ping/pong x hi/lo = 4 planes x 3,440 B fit the f16 kernel's two
-//     private buffers (2 x 7,760 B);
-//   * weights: hi and lo fragments stream from L2 through a rolling window of WDEPTH k-steps (the tower's
-//     18 x n_layers k-steps are one linear sequence in memory, so the window rolls across layer boundaries);
+//     stored, so a plane needs 43 rows of FW + 8 halves: ping/pong (x hi/lo) planes fit the two private
+//     buffers of the two-position forward (2 x 7,760 B) for <32, precise> (4 x 3,440 B) and <64, fp16>
+//     (2 x 6,192 B); <64, precise> does not fit and is not offered;
+//   * weights: fragments stream from L2 through a rolling window of WDEPTH k-steps (the tower's k-steps are
+//     one linear sequence in memory, so the window rolls across layer boundaries);
 //   * heads and MLPs as in net_forward_wave (fp32 VALU), fed with the folded fp32 activations.
 // ------------------------------------------------------------------------------------------------
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
 constexpr int PROWS = PIX + 1;               // 42 real rows + the zero row
-constexpr int PPLANE = PROWS * CS;           // halves per plane (3,440 B)
-constexpr int WDEPTH = 6;                    // k-steps of weights in flight (divides KSTEPS: the window's slot of k-step s is s % 6 in every layer)
-static_assert(4 * PPLANE <= 2 * WACT, "the four planes of the precise forward must fit the wave's two private buffers");
-static_assert(KSTEPS % WDEPTH == 0, "rolling weight window");
+constexpr int WDEPTH = 6;                    // k-steps of weights in flight (divides the k-steps of a layer: a k-step's window slot is s % 6 in every layer)
+template <int FW> struct Wave1Geom {
+    static constexpr int CB = FW / 32;            // cout blocks of 32 (one MFMA each)
+    static constexpr int KPT = FW / 16;           // k-steps per tap
+    static constexpr int KS = 9 * KPT;            // k-steps per 3x3 conv layer
+    static constexpr int CSF = FW + 8;            // halves per LDS row: (FW + 8) * 2 B keeps ds_read_b128 conflict free for 32 and 64
+    static constexpr int PLANE = PROWS * CSF;     // halves per plane
+    static_assert(FW == 32 || FW == 64, "supported widths");
+    static_assert(KS % WDEPTH == 0, "rolling weight window");
+};
+constexpr bool wave1_supported(int fw, bool precise) { return (fw == 32) || (fw == 64 && !precise); }
 
-__device__ __forceinline__ void split_store(const floatx16 &hi, const floatx16 &lo, _Float16 *dh, _Float16 *dl, int rowoff, int h, bool real)
+template <int FW, bool PRECISE>
+__device__ __forceinline__ void wave1_store(const floatx16 &hi, const floatx16 &lo, _Float16 *dh, _Float16 *dl, int off, bool real)
 {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         half4 oh, ol;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float y = lrelu(hi[4 * q + i] + lo[4 * q + i] * LO_INV);
+            const float y = PRECISE ? lrelu(hi[4 * q + i] + lo[4 * q + i] * LO_INV) : lrelu(hi[4 * q + i]);
             const _Float16 yh = (_Float16)y;
             oh[i] = yh;
-            ol[i] = (_Float16)((y - (float)yh) * LO_SCALE);
+            if (PRECISE) ol[i] = (_Float16)((y - (float)yh) * LO_SCALE);
         }
         if (real) {
-            *reinterpret_cast<half4 *>(dh + rowoff + 8 * q + 4 * h) = oh;
-            *reinterpret_cast<half4 *>(dl + rowoff + 8 * q + 4 * h) = ol;
+            *reinterpret_cast<half4 *>(dh + off + 8 * q) = oh;
+            if (PRECISE) *reinterpret_cast<half4 *>(dl + off + 8 * q) = ol;
         }
     }
 }
 
-__device__ __forceinline__ void net_forward_wave_precise(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds,
-                                                         uint64_t b0, uint64_t b1, float *__restrict__ values,
-                                                         float *__restrict__ priors, int out, unsigned long long *stamps = nullptr)
+template <int FW, bool PRECISE>
+__device__ __forceinline__ void net_forward_wave1(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds,
+                                                  uint64_t b0, uint64_t b1, float *__restrict__ values,
+                                                  float *__restrict__ priors, int out, unsigned long long *stamps = nullptr)
 {
+    using G = Wave1Geom<FW>;
+    constexpr int CB = G::CB, KPT = G::KPT, KS = G::KS, CSF = G::CSF, PLANE = G::PLANE;
+    static_assert(wave1_supported(FW, PRECISE), "this width / precision does not fit the wave's private LDS");
+    static_assert((PRECISE ? 4 : 2) * PLANE <= 2 * WACT, "planes must fit the wave's two private buffers");
     int lane_ = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_));     // see net_forward_wave_nt: keep lane-derived addresses out of the caller's loop
     const int lane = lane_;
@@ -723,27 +743,40 @@ __device__ __forceinline__ void net_forward_wave_precise(const NetDev &nd, _Floa
     auto stamp = [&](int i) { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); };
     stamp(0);
     const int n_layers = 2 * nd.n_res;
-    _Float16 *const p0h = buf, *const p0l = buf + PPLANE, *const p1h = buf + 2 * PPLANE, *const p1l = buf + 3 * PPLANE;
-    auto load_bias = [&](const float *b, float4 (&o)[4]) {
+    // planes: ping (p0) and pong (p1), each hi (and lo when PRECISE)
+    _Float16 *const p0h = buf, *const p0l = buf + PLANE;
+    _Float16 *const p1h = buf + (PRECISE ? 2 : 1) * PLANE, *const p1l = buf + 3 * PLANE;
+    auto load_bias = [&](const float *b, float4 (&o)[CB][4]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = *reinterpret_cast<const float4 *>(b + 8 * q + 4 * h);
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[cb][q] = *reinterpret_cast<const float4 *>(b + 32 * cb + 8 * q + 4 * h);
     };
-    // rolling weight window, primed with the first WDEPTH k-steps of the tower
-    half8 wh[WDEPTH], wl[WDEPTH];
+    // rolling weight window, primed with the first WDEPTH k-steps of the tower; fragment (k-step t, cout block cb)
+    // lives at [(t * CB + cb) * 64 + lane]
+    half8 wh[WDEPTH][CB], wl[WDEPTH][CB];
     const half8 *wph = nd.conv_w + lane, *wpl = nd.conv_wl + lane;
-    const int total_steps = n_layers * KSTEPS;
+    const int total_steps = n_layers * KS;
 #pragma unroll
     for (int s = 0; s < WDEPTH; ++s) {
         const int t = s < total_steps ? s : 0;
-        wh[s] = wph[t * 64];
-        wl[s] = wpl[t * 64];
-    }
-    half8 swh[3], swl[3];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) { swh[s] = nd.stem_w[s * 64 + lane]; swl[s] = nd.stem_wl[s * 64 + lane]; }
-    float4 bias[4];
+        for (int cb = 0; cb < CB; ++cb) {
+            wh[s][cb] = wph[(t * CB + cb) * 64];
+            if (PRECISE) wl[s][cb] = wpl[(t * CB + cb) * 64];
+        }
+    }
+    half8 swh[3][CB], swl[3][CB];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            swh[s][cb] = nd.stem_w[(s * CB + cb) * 64 + lane];
+            if (PRECISE) swl[s][cb] = nd.stem_wl[(s * CB + cb) * 64 + lane];
+        }
+    float4 bias[CB][4];
     load_bias(bias_lds, bias);
-    // input planes (board.py:147-154), 4 halves per row, in plane p1h (the tower writes it only after the stem)
+    // input planes (board.py:147-154), 4 halves per row, at the start of p1h (the tower writes it only after the stem)
     _Float16 *inp = p1h;
     if (lane <= PIX) {
         half4 v = {};
@@ -756,9 +789,10 @@ __device__ __forceinline__ void net_forward_wave_precise(const NetDev &nd, _Floa
         }
         *reinterpret_cast<half4 *>(inp + lane * 4) = v;   // lane == PIX: the zero row of the planes
     }
-    if (lane < CS) {   // the zero rows of the four planes (the input planes above occupy the first rows of p1h only)
-        p0h[PIX * CS + lane] = (_Float16)0.0f; p0l[PIX * CS + lane] = (_Float16)0.0f;
-        p1h[PIX * CS + lane] = (_Float16)0.0f; p1l[PIX * CS + lane] = (_Float16)0.0f;
+    for (int i = lane; i < CSF; i += 64) {   // the zero rows of the planes (the input planes occupy the first rows of p1h only)
+        p0h[PIX * CSF + i] = (_Float16)0.0f;
+        p1h[PIX * CSF + i] = (_Float16)0.0f;
+        if (PRECISE) { p0l[PIX * CSF + i] = (_Float16)0.0f; p1l[PIX * CSF + i] = (_Float16)0.0f; }
     }
     // row geometry: tile ti holds rows 32 ti + r32; rows >= 42 read the zero row and store nothing
     uint32_t rsel2[2][5];
@@ -769,21 +803,21 @@ __device__ __forceinline__ void net_forward_wave_precise(const NetDev &nd, _Floa
         const int rg = ti * 32 + r32;
         const int y = rg / 7, x = rg - y * 7;
         real[ti] = rg < PIX;
-        rbase[ti] = (real[ti] ? rg : PIX) * CS;
+        rbase[ti] = (real[ti] ? rg : PIX) * CSF;
 #pragma unroll
         for (int j = 0; j < 5; ++j) rsel2[ti][j] = 0;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
             const int ok = -(int)(real[ti] && (unsigned)(y + dy) < 6u && (unsigned)(x + dx) < 7u);
-            const uint32_t off = (uint32_t)((((rg + dy * 7 + dx) & ok) | (PIX & ~ok)) * CS + 8 * h);
+            const uint32_t off = (uint32_t)((((rg + dy * 7 + dx) & ok) | (PIX & ~ok)) * CSF + 8 * h);
             rsel2[ti][tap >> 1] |= off << (16 * (tap & 1));
         }
     }
     auto rsel = [&](int ti, int tap) -> int { return (int)((rsel2[ti][tap >> 1] >> (16 * (tap & 1))) & 0xffffu); };
     // ------------------------------------------------------------------ stem: planes -> p0
     {
-        floatx16 ah[2], al[2];
+        floatx16 ah[2][CB], al[2][CB];
         half4 v[2][6];
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
@@ -797,8 +831,8 @@ __device__ __forceinline__ void net_forward_wave_precise(const NetDev &nd, _Floa
                 const int row = ((rg + (ty - 1) * 7 + tx - 1) & ok) | (PIX & ~ok);
                 v[ti][i] = *reinterpret_cast<const half4 *>(inp + row * 4);
             }
-            ah[ti] = acc_from_bias(bias);
-            al[ti] = floatx16{};
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) { ah[ti][cb] = acc_from_bias(bias[cb]); al[ti][cb] = floatx16{}; }
         }
 #pragma unroll
         for (int s = 0; s < 3; ++s)
@@ -807,11 +841,17 @@ __device__ __forceinline__ void net_forward_wave_precise(const NetDev &nd, _Floa
                 half8 bf;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { bf[j] = v[ti][2 * s][j]; bf[4 + j] = v[ti][2 * s + 1][j]; }
-                ah[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(swh[s], bf, ah[ti], 0, 0, 0);
-                al[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(swl[s], bf, al[ti], 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    ah[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(swh[s][cb], bf, ah[ti][cb], 0, 0, 0);
+                    if (PRECISE) al[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(swl[s][cb], bf, al[ti][cb], 0, 0, 0);
+                }
             }
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) split_store(ah[ti], al[ti], p0h, p0l, rbase[ti], h, real[ti]);
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+                wave1_store<FW, PRECISE>(ah[ti][cb], al[ti][cb], p0h, p0l, rbase[ti] + 32 * cb + 4 * h, real[ti]);
     }
     stamp(1);
     // ------------------------------------------------------------------ residual tower
@@ -819,42 +859,52 @@ __device__ __forceinline__ void net_forward_wave_precise(const NetDev &nd, _Floa
         const bool second = L & 1;
         const _Float16 *sh = second ? p1h : p0h, *sl = second ? p1l : p0l;
         _Float16 *dh = second ? p0h : p1h, *dl = second ? p0l : p1l;
-        floatx16 ah[2], al[2];
-        load_bias(bias_lds + F * (1 + L), bias);
+        floatx16 ah[2][CB], al[2][CB];
+        load_bias(bias_lds + FW * (1 + L), bias);
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) { ah[ti] = acc_from_bias(bias); al[ti] = floatx16{}; }
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) { ah[ti][cb] = acc_from_bias(bias[cb]); al[ti][cb] = floatx16{}; }
         half8 bh[2], bl[2], nh[2], nl[2];
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
             bh[ti] = *reinterpret_cast<const half8 *>(sh + rsel(ti, 0));
-            bl[ti] = *reinterpret_cast<const half8 *>(sl + rsel(ti, 0));
+            if (PRECISE) bl[ti] = *reinterpret_cast<const half8 *>(sl + rsel(ti, 0));
         }
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            if (s + 1 < KSTEPS) {
+        for (int s = 0; s < KS; ++s) {
+            if (s + 1 < KS) {
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti) {
-                    const int o = rsel(ti, (s + 1) >> 1) + ((s + 1) & 1) * 16;
+                    const int o = rsel(ti, (s + 1) / KPT) + ((s + 1) % KPT) * 16;
                     nh[ti] = *reinterpret_cast<const half8 *>(sh + o);
-                    nl[ti] = *reinterpret_cast<const half8 *>(sl + o);
+                    if (PRECISE) nl[ti] = *reinterpret_cast<const half8 *>(sl + o);
                 }
             }
-            const half8 cwh = wh[s % WDEPTH], cwl = wl[s % WDEPTH];
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                ah[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh, bh[ti], ah[ti], 0, 0, 0);
-                al[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwl, bh[ti], al[ti], 0, 0, 0);
-                al[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh, bl[ti], al[ti], 0, 0, 0);
+            for (int cb = 0; cb < CB; ++cb) {
+                const half8 cwh = wh[s % WDEPTH][cb];
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti) {
+                    ah[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh, bh[ti], ah[ti][cb], 0, 0, 0);
+                    if (PRECISE) {
+                        al[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s % WDEPTH][cb], bh[ti], al[ti][cb], 0, 0, 0);
+                        al[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh, bl[ti], al[ti][cb], 0, 0, 0);
+                    }
+                }
             }
-            {   // refill the window slot just used with k-step (L*18 + s + WDEPTH) of the tower; unconditional
+            {   // refill the window slot just used with k-step (L*KS + s + WDEPTH) of the tower; unconditional
                 // (past the end it re-reads step 0: a branch around the loads would drain vmcnt)
-                int t = L * KSTEPS + s + WDEPTH;
+                int t = L * KS + s + WDEPTH;
                 t = t < total_steps ? t : 0;
-                wh[s % WDEPTH] = wph[t * 64];
-                wl[s % WDEPTH] = wpl[t * 64];
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    wh[s % WDEPTH][cb] = wph[(t * CB + cb) * 64];
+                    if (PRECISE) wl[s % WDEPTH][cb] = wpl[(t * CB + cb) * 64];
+                }
             }
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti) { bh[ti] = nh[ti]; bl[ti] = nl[ti]; }
+            for (int ti = 0; ti < 2; ++ti) { bh[ti] = nh[ti]; if (PRECISE) bl[ti] = nl[ti]; }
         }
         if (second) {   // + block input (lives in dh/dl): identity MFMAs keep it exact in both accumulators
             half8 idf[2];
@@ -863,45 +913,52 @@ __device__ __forceinline__ void net_forward_wave_precise(const NetDev &nd, _Floa
 #pragma unroll
                 for (int j = 0; j < 8; ++j) idf[s][j] = (_Float16)((16 * s + 8 * h + j) == r32 ? 1.0f : 0.0f);
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                const half8 xh0 = *reinterpret_cast<const half8 *>(dh + rbase[ti] + 8 * h);
-                const half8 xh1 = *reinterpret_cast<const half8 *>(dh + rbase[ti] + 16 + 8 * h);
-                const half8 xl0 = *reinterpret_cast<const half8 *>(dl + rbase[ti] + 8 * h);
-                const half8 xl1 = *reinterpret_cast<const half8 *>(dl + rbase[ti] + 16 + 8 * h);
-                ah[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[0], xh0, ah[ti], 0, 0, 0);
-                ah[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[1], xh1, ah[ti], 0, 0, 0);
-                al[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[0], xl0, al[ti], 0, 0, 0);
-                al[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[1], xl1, al[ti], 0, 0, 0);
-            }
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const int o = rbase[ti] + 32 * cb + 8 * h;
+                    const half8 xh0 = *reinterpret_cast<const half8 *>(dh + o), xh1 = *reinterpret_cast<const half8 *>(dh + o + 16);
+                    ah[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[0], xh0, ah[ti][cb], 0, 0, 0);
+                    ah[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[1], xh1, ah[ti][cb], 0, 0, 0);
+                    if (PRECISE) {
+                        const half8 xl0 = *reinterpret_cast<const half8 *>(dl + o), xl1 = *reinterpret_cast<const half8 *>(dl + o + 16);
+                        al[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[0], xl0, al[ti][cb], 0, 0, 0);
+                        al[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[1], xl1, al[ti][cb], 0, 0, 0);
+                    }
+                }
         }
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) split_store(ah[ti], al[ti], dh, dl, rbase[ti], h, real[ti]);
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+                wave1_store<FW, PRECISE>(ah[ti][cb], al[ti][cb], dh, dl, rbase[ti] + 32 * cb + 4 * h, real[ti]);
         if (L < 6) stamp(2 + L);
     }
     stamp(8);
     // tower output is in p0 (n_layers is even)
-    // ------------------------------------------------------------------ 1x1 head convs
+    // ------------------------------------------------------------------ 1x1 head convs (K = FW: KPT k-steps)
     float *hs = reinterpret_cast<float *>(p1h);   // [HSTR] fp32: value plane 0..41, policy planes 42..125 (p1 is free)
     {
-        const half8 hwh0 = nd.head_w[lane], hwh1 = nd.head_w[64 + lane], hwl0 = nd.head_wl[lane], hwl1 = nd.head_wl[64 + lane];
         const float hb0 = nd.head_b[0], hb1 = nd.head_b[1], hb2 = nd.head_b[2];
         float o0[2], o1[2], o2[2];
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
-            const half8 xh0 = *reinterpret_cast<const half8 *>(p0h + rbase[ti] + 8 * h);
-            const half8 xh1 = *reinterpret_cast<const half8 *>(p0h + rbase[ti] + 16 + 8 * h);
-            const half8 xl0 = *reinterpret_cast<const half8 *>(p0l + rbase[ti] + 8 * h);
-            const half8 xl1 = *reinterpret_cast<const half8 *>(p0l + rbase[ti] + 16 + 8 * h);
             floatx16 a = {}, b = {};
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwh0, xh0, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwh1, xh1, a, 0, 0, 0);
-            b = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwl0, xh0, b, 0, 0, 0);
-            b = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwl1, xh1, b, 0, 0, 0);
-            b = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwh0, xl0, b, 0, 0, 0);
-            b = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwh1, xl1, b, 0, 0, 0);
-            o0[ti] = lrelu(a[0] + b[0] * LO_INV + hb0);
-            o1[ti] = lrelu(a[1] + b[1] * LO_INV + hb1);
-            o2[ti] = lrelu(a[2] + b[2] * LO_INV + hb2);
+#pragma unroll
+            for (int s = 0; s < KPT; ++s) {
+                const half8 hwh = nd.head_w[s * 64 + lane];
+                const half8 xh = *reinterpret_cast<const half8 *>(p0h + rbase[ti] + 16 * s + 8 * h);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwh, xh, a, 0, 0, 0);
+                if (PRECISE) {
+                    const half8 hwl = nd.head_wl[s * 64 + lane];
+                    const half8 xl = *reinterpret_cast<const half8 *>(p0l + rbase[ti] + 16 * s + 8 * h);
+                    b = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwl, xh, b, 0, 0, 0);
+                    b = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwh, xl, b, 0, 0, 0);
+                }
+            }
+            o0[ti] = lrelu(a[0] + (PRECISE ? b[0] * LO_INV : 0.0f) + hb0);
+            o1[ti] = lrelu(a[1] + (PRECISE ? b[1] * LO_INV : 0.0f) + hb1);
+            o2[ti] = lrelu(a[2] + (PRECISE ? b[2] * LO_INV : 0.0f) + hb2);
         }
         // every lane has read the tower output and p1 is dead: the head planes may overwrite p1h
 #pragma unroll
@@ -956,13 +1013,25 @@ __device__ __forceinline__ void net_forward_wave_precise(const NetDev &nd, _Floa
     stamp(10);
 }
 
-constexpr int BIAS_LDS_LAYERS = 128;                        // c4_net_create accepts up to 64 residual blocks
-constexpr int BIAS_LDS_FLOATS = F * (1 + BIAS_LDS_LAYERS);  // 16.5 KB
+// net mode of a NetDev, as the kernels are specialised
+constexpr int NETMODE_F32_2POS = 0;   // 32 filters, fp16 storage: net_forward_wave / net_forward_block (two positions per pass)
+constexpr int NETMODE_F32_PRECISE = 1;
+constexpr int NETMODE_F64 = 2;        // 64 filters, fp16 storage, one position per pass
+template <int MODE>
+__device__ __forceinline__ void net_forward_wave1_mode(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds, uint64_t b0,
+                                                       uint64_t b1, float *__restrict__ values, float *__restrict__ priors, int out,
+                                                       unsigned long long *stamps = nullptr)
+{
+    if (MODE == NETMODE_F64) net_forward_wave1<64, false>(nd, buf, mlp, bias_lds, b0, b1, values, priors, out, stamps);
+    else net_forward_wave1<32, true>(nd, buf, mlp, bias_lds, b0, b1, values, priors, out, stamps);
+}
+
+constexpr int BIAS_LDS_FLOATS = 32 * (1 + 128);   // 16.5 KB: stem + conv biases of up to 64 residual blocks at 32 filters, 32 at 64
 // cooperative fill of the LDS bias copy by the whole workgroup (the caller synchronises afterwards)
 __device__ __forceinline__ void stage_bias_lds(const NetDev &nd, float *bias_lds)
 {
-    const int n_layers = 2 * nd.n_res;
-    for (int i = threadIdx.x; i < F * (1 + n_layers); i += NTHREADS) bias_lds[i] = i < F ? nd.stem_b[i] : nd.conv_b[i - F];
+    const int n_layers = 2 * nd.n_res, fw = nd.filters;
+    for (int i = threadIdx.x; i < fw * (1 + n_layers); i += NTHREADS) bias_lds[i] = i < fw ? nd.stem_b[i] : nd.conv_b[i - fw];
 }
 __device__ __forceinline__ void net_forward_wave(const NetDev &nd, _Float16 *a0, _Float16 *a1, const float4 *mlp,
                                                  const float *bias_lds, uint64_t bA0, uint64_t bA1, uint64_t bB0, uint64_t bB1,

@@ -299,15 +299,37 @@ def test_precise_fused_selfplay_equals_separate_kernels(oracle):
     assert out[0] == out[1]
 
 
-def test_wide_net_falls_back_to_pytorch_plan():
-    """example_config's 64-filter / 6-block / 6-fc net (data/example_config.py:8-16): no fused kernel for
-    that width, the factory returns the PyTorch-ROCm plan and self-play works unchanged."""
+def test_wide_net_runs_on_the_fused_kernel(oracle):
+    """example_config's 64-filter / 6-block / 6-fc net (data/example_config.py:8-16) runs on the fused one-position
+    forward (two cout blocks per MFMA step); an unsupported width still gets the PyTorch-ROCm plan; the games of
+    the wide net replay on the oracle from the device's evaluation cache."""
+    from connect4_amd import _lib as L
     from connect4_amd.config import MCTSConfig
     from connect4_amd.fused_net import FusedNet, make_selfplay_net
     from connect4_amd.net import InferenceNet, NetConfig, random_init_state_dict
-    from connect4_amd.selfplay import generate_games
+    from connect4_amd.selfplay import SelfPlay, generate_games
+    from oracle.replay import oracle_config, random_tapes, replay_game
     wide = make_selfplay_net(random_init_state_dict(NetConfig(filters=64, n_fc_layers=6, n_residuals=6), seed=0))
-    assert isinstance(wide, InferenceNet)
+    assert isinstance(wide, FusedNet) and wide.config.filters == 64
     assert isinstance(make_selfplay_net(random_init_state_dict(seed=0)), FusedNet)
-    games = generate_games(MCTSConfig.self_play(16), wide, n_games=8, n_slots=8, seed=0)
+    other = make_selfplay_net(random_init_state_dict(NetConfig(filters=48, n_residuals=1), seed=0))
+    assert isinstance(other, InferenceNet)
+    games = generate_games(MCTSConfig.self_play(16), other, n_games=8, n_slots=8, seed=0)
     assert len(games) == 8 and all(g.result is not None for g in games)
+    with pytest.raises(L.EngineError):       # the hi/lo planes of 64 filters do not fit a wave's LDS: refused, not approximated
+        FusedNet(random_init_state_dict(NetConfig(filters=64), seed=0), precision="f32x3")
+    cfg = MCTSConfig.self_play(24)
+    noise, u = random_tapes(40, cfg.root_dirichlet_alpha, seed=4)
+    sp = SelfPlay(wide, 40, cfg, seed=0, games_target=40, record_capacity_games=40, use_graph=False, fused_loop=True,
+                  steps_per_launch=16, rng_mode=L.RNG_TAPE)
+    sp.engine.set_tapes(noise, u)
+    sp.engine.reset()
+    for _ in range(400):
+        sp.run_steps(64)
+        if sp.stats()["active_slots"] == 0:
+            break
+    recs = sp.engine.drain_games()
+    assert len(recs) == 40 and sp.stats()["bad_evals"] == 0
+    for r in recs[:5]:
+        replay_game(oracle_config(cfg), sp.engine, wide, r, noise[r.game_id], u[r.game_id])
+    sp.close()

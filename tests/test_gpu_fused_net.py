@@ -105,3 +105,26 @@ def test_precise_net_vs_pytorch_fp32(oracle, n):
         dv, dp = np.abs(v - rv.cpu().numpy()).max(), np.abs(p - rp.cpu().numpy()).max()
         print("n=%d n_res=%d precise vs torch fp32: max |dv| %.3g  max |dp| %.3g" % (n, n_res, dv, dp))
         assert dv < 2e-5 and dp < 2e-5
+
+
+# ---------------------------------------------------------------- 64 filters (data/example_config.py:8-16)
+@pytest.mark.parametrize("n", [1, 8, 9, 1031])
+def test_fused_net_64_filters_vs_pytorch_fp32(oracle, n):
+    """The reference's other shipped width: 64 filters, 6 residual blocks, 6 value-head Linear layers -- fused
+    one-position forward (fp16 storage) vs the fp32 PyTorch-ROCm plan, same stated tolerance as the 32-filter
+    fp16 kernel (2e-2); both entry points run the one implementation."""
+    from connect4_amd.engine import board_planes
+    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.net import InferenceNet, NetConfig, random_init_state_dict
+    for cfg in (NetConfig(filters=64, n_fc_layers=6, n_residuals=6), NetConfig(filters=64, n_residuals=2)):
+        sd = random_init_state_dict(cfg, seed=3)
+        c0, c1 = random_positions(oracle, n, seed=n)
+        ref = InferenceNet(sd, device="cuda", dtype=torch.float32)
+        rv, rp = ref(torch.from_numpy(board_planes(c0, c1)).cuda())
+        net = FusedNet(sd)
+        v, p = net.evaluate_bits(c0, c1)
+        wv, wp = net.evaluate_bits(c0, c1, wave=True)
+        dv, dp = np.abs(v - rv.cpu().numpy()).max(), np.abs(p - rp.cpu().numpy()).max()
+        print("n=%d 64f/%dres fused vs torch fp32: max |dv| %.3g  max |dp| %.3g" % (n, cfg.n_residuals, dv, dp))
+        assert dv < 2e-2 and dp < 2e-2
+        assert np.array_equal(v, wv) and np.array_equal(p, wp)

@@ -76,7 +76,7 @@ def parse_args(argv=None):
                     help="fused net arithmetic: f16 storage / f32 accumulate, or the reference-precision split")
     ap.add_argument("--net-dtype", default=None, choices=["f32", "f16", "bf16"], help="torch net only (default f32)")
     ap.add_argument("--steps-per-graph", type=int, default=8)
-    ap.add_argument("--max-inner", type=int, default=8, help="evaluator-free simulations a slot may run per tree call (0 = engine default)")
+    ap.add_argument("--max-inner", type=int, default=32, help="evaluator-free simulations a slot may run per tree call (0 = engine default)")
     ap.add_argument("--eval-cache", type=int, default=0, help="log2 entries of the evaluation cache (0 auto, -1 off)")
     ap.add_argument("--level-budget", type=int, default=0, help="descent levels per slot per launch (0 unlimited)")
     ap.add_argument("--time-budget", type=int, default=80000,

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libc4engine.so")
+# C4_ENGINE_LIB: tuning aid -- load another build of the same library (A/B runs of kernel variants in one process tree)
+LIB_PATH = os.environ.get("C4_ENGINE_LIB") or os.path.join(_HERE, "libc4engine.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "c4_engine.h")
 
 ABI_VERSION = 2
@@ -109,6 +110,7 @@ SIGNATURES = {
     "c4_board_fliplr": (C.c_int, [C.c_int, _u64p, _u64p, C.c_int32, _u64p, _u64p]),
     "c4_board_centre_value": (C.c_int, [C.c_int, _u64p, _u64p, C.c_int32, _f64p]),
     "c4_debug_stamps": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
+    "c4_debug_fused_net_stamps": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
     "c4_net_create": (C.c_int, [C.c_int, _P(NetDesc), _P(C.c_void_p)]),
     "c4_net_destroy": (C.c_int, [C.c_void_p]),
     "c4_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),

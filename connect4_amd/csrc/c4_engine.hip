@@ -37,6 +37,23 @@
 #include "c4_board.h"
 #include "c4_net_dev.h"
 
+#ifndef C4_DEADLINE_EVERY
+#define C4_DEADLINE_EVERY 1   // a tree call looks at the clock every this many simulations (power of two; 4 measured no faster)
+#endif
+#ifndef C4_TERMQ
+#define C4_TERMQ 1            // q of a terminal node holds its exact result from creation on
+#endif
+#ifndef C4_FUSED_NET_STAMPS
+#define C4_FUSED_NET_STAMPS 0 // diagnostic build only (-DC4_FUSED_NET_STAMPS=1, tools/wave_stamps.py): stamps of the network pass
+                              // inside the fused kernel; the extra pointer costs the production kernel 3 %
+#endif
+#ifndef C4_ASM_PICK
+#define C4_ASM_PICK 1         // butterfly step written out in assembly (compare, select and DPP moves in one block)
+#endif
+#ifndef C4_EARLY_REQUEST
+#define C4_EARLY_REQUEST 1   // software-pipelined level loop (tuning aid: -DC4_EARLY_REQUEST=0 restores the plain loop)
+#endif
+
 namespace {
 
 using namespace c4;
@@ -278,12 +295,17 @@ __device__ inline double rng_gamma(uint64_t seed, long long gid, uint32_t ply, u
 }
 
 // tree.py:27-44 + utils.py:33-34: value of a child from `side`'s point of view (branch-free).
+// terminal: the exact result, not a running mean -- it is what q holds for a terminal node from its creation on
+// (every visit adds that same value, so w / n reproduces it exactly); visited: q = value_sum / visit_count
+// (refreshed by every backup); unknown: 0.0 for either side ("assume lost")
 __device__ __forceinline__ double child_value_for(uint32_t status, uint32_t n, double q, int side)
 {
     const bool term = status >= ST_XWIN;
-    // terminal: exact result, not the running mean; visited: q = value_sum / visit_count (refreshed by
-    // every backup); unknown: 0.0 for either side ("assume lost")
+#if C4_TERMQ
+    const double v = q;
+#else
     const double v = term ? 0.5 * (double)(status - ST_XWIN) : q;
+#endif
     const double sv = side == 0 ? v : 1.0 - v;
     return (term || n > 0) ? sv : 0.0;
 }
@@ -354,6 +376,41 @@ struct Pick {      // a candidate child with its record riding along
                  : [n] "+v"(n), [i] "+v"(info), [wl] "+v"(wl), [wh] "+v"(wh)                              \
                  : [m] "s"(m)                                                                             \
                  : "vcc")
+#if C4_ASM_PICK
+// keep-own = (s > os) | (s == os & k >= ok) is computed as wave masks (v_cmp into SGPR pairs + two scalar ops)
+// and goes to VCC once; the own/partner selects of score and index and the v_cndmask_b32_dpp selects of the
+// fields that ride along then all read VCC in one block.  (A ballot of the boolean would be re-materialised
+// by the compiler with a v_cndmask + v_cmp per step.)
+#define C4_PICK_SELECT(CTRL)                                                                             \
+    asm volatile("s_mov_b64 vcc, %[m]\n"                                                                 \
+                 "s_nop 0\n"                                                                             \
+                 "v_cndmask_b32 %[sl], %[ol], %[sl], vcc\n"                                               \
+                 "v_cndmask_b32 %[sh], %[oh], %[sh], vcc\n"                                               \
+                 "v_cndmask_b32 %[k], %[ok], %[k], vcc\n"                                                 \
+                 "v_cndmask_b32_dpp %[n], %[n], %[n], vcc " CTRL " row_mask:0xf bank_mask:0xf\n"          \
+                 "v_cndmask_b32_dpp %[i], %[i], %[i], vcc " CTRL " row_mask:0xf bank_mask:0xf\n"          \
+                 "v_cndmask_b32_dpp %[wl], %[wl], %[wl], vcc " CTRL " row_mask:0xf bank_mask:0xf\n"       \
+                 "v_cndmask_b32_dpp %[wh], %[wh], %[wh], vcc " CTRL " row_mask:0xf bank_mask:0xf\n"       \
+                 : [sl] "+v"(sl), [sh] "+v"(sh), [k] "+v"(k), [n] "+v"(n), [i] "+v"(info), [wl] "+v"(wl), [wh] "+v"(wh) \
+                 : [m] "s"(m), [ol] "v"(ol), [oh] "v"(oh), [ok] "v"(ok)                                     \
+                 : "vcc")
+template <int CTRL>
+__device__ __forceinline__ void pick_step(double &s, int &k, uint32_t &n, uint32_t &info, uint32_t &wl, uint32_t &wh)
+{
+    const uint64_t sb = (uint64_t)__double_as_longlong(s);
+    uint32_t sl = (uint32_t)sb, sh = (uint32_t)(sb >> 32);
+    const uint32_t ol = dpp_u32<CTRL>(sl), oh = dpp_u32<CTRL>(sh);
+    const int ok = (int)dpp_u32<CTRL>((uint32_t)k);
+    const double os = __longlong_as_double((long long)(((uint64_t)oh << 32) | ol));
+    const unsigned long long m = __builtin_amdgcn_fcmp(s, os, 2 /* ogt */) |
+                                 (__builtin_amdgcn_fcmp(s, os, 1 /* oeq */) & __builtin_amdgcn_sicmp(k, ok, 39 /* sge */));
+    if (CTRL == 0xB1) C4_PICK_SELECT("quad_perm:[1,0,3,2]");
+    else if (CTRL == 0x4E) C4_PICK_SELECT("quad_perm:[2,3,0,1]");
+    else C4_PICK_SELECT("row_half_mirror");
+    s = __longlong_as_double((long long)(((uint64_t)sh << 32) | sl));
+}
+#undef C4_PICK_SELECT
+#else
 template <int CTRL>
 __device__ __forceinline__ void pick_step(double &s, int &k, uint32_t &n, uint32_t &info, uint32_t &wl, uint32_t &wh)
 {
@@ -367,6 +424,7 @@ __device__ __forceinline__ void pick_step(double &s, int &k, uint32_t &n, uint32
     else if (CTRL == 0x4E) C4_DPP_SELECT("quad_perm:[2,3,0,1]");
     else C4_DPP_SELECT("row_half_mirror");
 }
+#endif
 #undef C4_DPP_SELECT
 __device__ __forceinline__ void group_pick(Pick &a)
 {
@@ -670,7 +728,8 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                 const uint32_t bit = (uint32_t)(H1 * lane + col_count(occ, lane));
                 const uint32_t cst = make_move(c0, c1, lane);
                 const uint32_t idx = base + k;
-                *pool.rec(idx) = Rec{0.0, 0.0, prn, 0u, pack_info(0, 0, cst, bit, 0)};
+                // q of a terminal child = its exact result (utils.py:19-22), see child_value_for
+                *pool.rec(idx) = Rec{0.0, cst >= ST_XWIN ? 0.5 * (double)(cst - ST_XWIN) : 0.0, prn, 0u, pack_info(0, 0, cst, bit, 0)};
             }
             if (lane == 0) {   // mcts.py:132-134: position_value / search_value.add(value)
                 if (l1_valid && pdepth == 1) {   // the leaf is a child of the root: keep the LDS copy current
@@ -822,7 +881,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
         // bound the launch: at most max_inner evaluator-free simulations per launch
         // a neighbour needs the network, or the launch's time quantum is over
         if (WAVE_SYNC && !resume && (__builtin_amdgcn_ballot_w64(true) != wave_mask0 ||
-                                     (long long)(__builtin_amdgcn_s_memtime() - deadline) > 0)) break;
+                                     ((inner & (C4_DEADLINE_EVERY - 1)) == 0 && (long long)(__builtin_amdgcn_s_memtime() - deadline) > 0))) break;
         if (!resume && (inner >= d.max_inner || levels_left <= 0 ||
                         (!WAVE_SYNC && d.time_budget > 0 && inner > 0 && (long long)(__builtin_amdgcn_s_memtime() - t_begin) > d.time_budget))) {
             st.capped += 1;
@@ -865,6 +924,77 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
         }
         int age = popc64(b0 | b1);
         unsigned long long lvl_t0 = (STAMPS && d.has_stamps) ? __builtin_amdgcn_s_memtime() : 0, lvl_wait = 0, lvl_alu = 0, lvl_cnt = 0;
+#if C4_EARLY_REQUEST
+        // Software-pipelined level loop: the sibling block (and score-table entry) of the NEXT level is requested
+        // the moment the argmax is known, in front of this level's bookkeeping (board replay, path entry,
+        // counters), so that bookkeeping runs under the load instead of in front of it.
+        Rec r = {};
+        double2 ab = {0.0, 0.0};
+        bool go = info_status(cinfo) == ST_EVALUATED && levels_left > 0;
+        if (go) {
+            const bool act0 = lane < (int)info_nchild(cinfo);
+            ab = d.tabAB[cN];
+            asm volatile("" ::: "memory");   // the score-table entry is requested first (its latency hides under the block's)
+            if (depth == 0 && l1_valid) {
+                if (act0) r = s_l1[gl][lane];                          // hot subtree: LDS
+            } else {
+                if (act0) r = *pool.rec(info_base(cinfo) + lane);      // two 16-byte loads per lane
+                if (depth == 0) {                                      // first descent of the launch: stage the block
+                    if (act0) s_l1[gl][lane] = r;
+                    l1_valid = true;
+                }
+            }
+        }
+        while (go) {
+            levels_left -= 1;
+            const uint32_t cb = info_base(cinfo), nc = info_nchild(cinfo), pf64 = info_pf64(cinfo);
+            if (cN == 1) st.expansions += 1;   // first descent through an evaluated node == expand_node
+            const bool act = lane < (int)nc;
+            const uint32_t n = r.n, inf = r.info;
+            const double w = r.w, q = r.q, p = r.p;
+            const double A = ab.x, B = ab.y;
+            if (STAMPS && d.has_stamps) {   // diagnostic: cycles this level still waits for its loads
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+                lvl_wait += t1 - lvl_t0;
+                lvl_t0 = t1;
+            }
+            const double V = child_value_for(info_status(inf), n, q, age & 1);
+            const double s = act ? ucb_score(A, B, n, p, V, pf64) : -std::numeric_limits<double>::infinity();
+            Pick best{s, act ? lane : -1, n, inf, w};
+            group_pick(best);                                   // mcts.py:141-142 max((score, child))
+            // ---- next level's request
+            go = info_status(best.info) == ST_EVALUATED && levels_left > 0;
+            Rec rn = {};
+            double2 abn = {0.0, 0.0};
+            if (go) {
+                abn = d.tabAB[best.n];
+                asm volatile("" ::: "memory");
+                if (lane < (int)info_nchild(best.info)) rn = *pool.rec(info_base(best.info) + lane);
+            }
+            // ---- this level's bookkeeping
+            cN = best.n;
+            cW = best.w;
+            cinfo = best.info;
+            cur = cb + (uint32_t)best.k;
+            {   // board.py:160-163 replayed: xor the recorded stone into the mover's colour
+                const uint64_t stone = 1ULL << info_bit(cinfo);
+                b0 ^= (age & 1) ? 0ULL : stone;
+                b1 ^= (age & 1) ? stone : 0ULL;
+            }
+            age += 1;
+            depth += 1;
+            if (lane == 0) s_path[gl][depth] = PathEntry{cur, cN, cW};
+            r = rn;
+            ab = abn;
+            if (STAMPS && d.has_stamps) {
+                const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+                lvl_alu += t2 - lvl_t0;
+                lvl_t0 = t2;
+                lvl_cnt += 1;
+            }
+        }
+#else
         while (info_status(cinfo) == ST_EVALUATED && levels_left > 0) {
             levels_left -= 1;
             const uint32_t cb = info_base(cinfo), nc = info_nchild(cinfo), pf64 = info_pf64(cinfo);
@@ -917,6 +1047,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                 lvl_cnt += 1;
             }
         }
+#endif
         if (STAMPS && d.has_stamps && blockIdx.x < 256 && threadIdx.x == 0) {
             d.cold->stamps[blockIdx.x * 8 + 7] = (lvl_wait << 32) | (lvl_alu & 0xffffffffu);
             d.cold->stamps[blockIdx.x * 8 + 6] = ((unsigned long long)lvl_cnt << 32) | depth;
@@ -1280,7 +1411,8 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
             for (int i = 0; i < cnt; i += WP) {
                 const int sa = pend_slot[i], sb = pend_slot[i + 1 < cnt ? i + 1 : i];
                 net_forward_wave(nd, &act[wv][0][0], &act[wv][1][0], mlp, s_bias, smem[sa].leaf0, smem[sa].leaf1, smem[sb].leaf0,
-                                 smem[sb].leaf1, min(WP, cnt - i), s_val, s_pri, sa, sb);
+                                 smem[sb].leaf1, min(WP, cnt - i), s_val, s_pri, sa, sb,
+                                 (C4_FUSED_NET_STAMPS && d.has_stamps && blockIdx.x < 16) ? d.cold->stamps + 2048 + (blockIdx.x * NWAVES + wv) * 16 : nullptr);
             }
         }
         lds_fence();   // answers (LDS) before the next tree_step reads them
@@ -1677,6 +1809,15 @@ extern "C" {
 int c4_abi_version(void) { return C4_ABI_VERSION; }
 
 /* diagnostic: s_memtime stamps of the last launch, [256 blocks][8] (needs C4_TREE_STAMPS=1 at create) */
+/* diagnostic: s_memtime stamps of the LAST network pass of each wave of workgroups 0..15 inside the last
+ * c4_selfplay_steps launch, [16][8 waves][16] (phases as c4_net_debug_stamps); needs C4_TREE_STAMPS=1 */
+int c4_debug_fused_net_stamps(c4_engine *e, unsigned long long *out)
+{
+    if (!e || !out || !e->cold.stamps) return C4_ESTATE;
+    if (hipDeviceSynchronize() != hipSuccess) return C4_EDEVICE;
+    return hipMemcpy(out, e->cold.stamps + 2048, 16 * 8 * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? C4_OK : C4_EDEVICE;
+}
+
 int c4_debug_stamps(c4_engine *e, unsigned long long *out)
 {
     if (!e || !out || !e->cold.stamps) return C4_ESTATE;
@@ -1808,7 +1949,7 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     }
     if (getenv("C4_TREE_STAMPS")) {
         unsigned long long *q = nullptr;
-        if (dev_alloc(e, &q, 256 * 8) == C4_OK) { (void)hipMemset(q, 0, 256 * 8 * 8); e->cold.stamps = q; }
+        if (dev_alloc(e, &q, 2 * 256 * 8) == C4_OK) { (void)hipMemset(q, 0, 2 * 256 * 8 * 8); e->cold.stamps = q; }
     }
     d.has_stamps = e->cold.stamps != nullptr;
     ALLOC(e->cold_dev, 1);

@@ -7,6 +7,10 @@
 #include <cstdint>
 #include <vector>
 
+#ifndef C4_BF_AHEAD
+#define C4_BF_AHEAD 1   // k-steps the wave-private forward reads its activation fragments ahead (tuning aid)
+#endif
+
 namespace c4net {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -554,21 +558,24 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
         // makes the compiler drain vmcnt in front of each of them
         const int Ln = L + 1 < n_layers ? L + 1 : 0;
         const half8 *wnext = nd.conv_w + (size_t)Ln * WCHUNKS + lane;
-        half8 bfc[NT], bfn[NT];
+        // B fragments (activations) are read from LDS C4_BF_AHEAD k-steps ahead of the MFMAs that consume them
+        // (ring of C4_BF_AHEAD + 1 fragment sets; all indices are compile-time after unrolling)
+        constexpr int PD = C4_BF_AHEAD;
+        half8 bq[PD + 1][NT];
 #pragma unroll
-        for (int ti = 0; ti < NT; ++ti) bfc[ti] = *reinterpret_cast<const half8 *>(src + rsel(ti, 0));
+        for (int a = 0; a < PD; ++a)
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) bq[a][ti] = *reinterpret_cast<const half8 *>(src + rsel(ti, a >> 1) + (a & 1) * 16);
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
-            if (s + 1 < KSTEPS) {
+            if (s + PD < KSTEPS) {
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
-                    bfn[ti] = *reinterpret_cast<const half8 *>(src + rsel(ti, (s + 1) >> 1) + ((s + 1) & 1) * 16);
+                    bq[(s + PD) % (PD + 1)][ti] = *reinterpret_cast<const half8 *>(src + rsel(ti, (s + PD) >> 1) + ((s + PD) & 1) * 16);
             }
 #pragma unroll
-            for (int ti = 0; ti < NT; ++ti) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s], bfc[ti], acc[ti], 0, 0, 0);
+            for (int ti = 0; ti < NT; ++ti) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s], bq[s % (PD + 1)][ti], acc[ti], 0, 0, 0);
             w[s] = wnext[s * 64];   // fragment s of the next layer, a whole layer ahead of its use
-#pragma unroll
-            for (int ti = 0; ti < NT; ++ti) bfc[ti] = bfn[ti];
         }
         if (L == 2) stamp(12);
         if (second) {

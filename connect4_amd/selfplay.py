@@ -164,9 +164,10 @@ class SelfPlay:
 
 def _play_to_completion(config, net, n_games, n_slots, seed, device, planes_dtype, poll_steps, use_graph, timeout_s):
     n_slots = min(n_games, n_slots or 4096)
+    fused = bool(getattr(net, "from_bitboards", False))
     sp = SelfPlay(net, n_slots, config, seed=seed, device=device, games_target=n_games,
                   record_capacity_games=n_games, planes_dtype=planes_dtype, use_graph=use_graph,
-                  fused_loop=bool(getattr(net, "from_bitboards", False)))
+                  fused_loop=fused, max_inner_iters=32 if fused else 8)
     t0 = time.time()
     try:
         while True:

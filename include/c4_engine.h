@@ -340,6 +340,10 @@ int c4_net_debug_stamps(c4_net *net, unsigned long long *out);
  * needs C4_TREE_STAMPS=1 in the environment when the engine is created, else C4_ESTATE. */
 int c4_debug_stamps(c4_engine *e, unsigned long long *out);
 
+/* diagnostic build aid: s_memtime stamps of the last network pass of every wave of workgroups 0..15 inside the last
+ * c4_selfplay_steps launch, [16][8][16] (phase order as c4_net_debug_stamps); needs C4_TREE_STAMPS=1, else C4_ESTATE. */
+int c4_debug_fused_net_stamps(c4_engine *e, unsigned long long *out);
+
 int c4_abi_version(void);
 
 #ifdef __cplusplus

@@ -341,6 +341,7 @@ def run_rank(args):
             "moves_per_sec": tot["moves"] / elapsed,
             "terminal_sim_fraction": tot["terminal_sims"] / max(1.0, sims),
             "bad_evals": tot["bad_evals"],
+            "net_evals_per_sec": (tot["leaf_evals"] - tot["eval_cache_hits"]) / elapsed,
             "eval_cache_hit_rate": tot["eval_cache_hits"] / max(1.0, tot["eval_cache_probes"]),
             "mean_leaf_depth": tot["depth_sum"] / max(1.0, sims),
             "timed_region_s": elapsed,

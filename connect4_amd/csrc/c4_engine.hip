@@ -1323,7 +1323,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_kernel(Dev d, c4n
 // wave-autonomous fused self-play kernel: like c4_selfplay_kernel, but there is no workgroup barrier
 // inside the step loop at all.  Every wave owns TS/8 slots and alternates
 //   tree_step for its slots until one of them needs the network (or max_inner simulations each),
-//   net_forward_wave on that wave's own leaves (two positions per pass, private LDS buffers),
+//   the wave-private network forward on that wave's own leaves (one position per pass, private LDS planes),
 // so a tree never waits for the deepest tree of the workgroup or for a full 16-row batch: the answer
 // is there ~20 k cycles after the miss.  Same games as every other path (the network arithmetic is
 // bit-identical to net_forward_block's).
@@ -1337,14 +1337,17 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
     const_dev &d = *(const_dev *)d_dev;   // engine description: scalar loads from constant memory at the point of use
     constexpr int SPW = TS / NWAVES;   // slots per wave
     static_assert(TS % NWAVES == 0 && SPW >= 1 && SPW <= 8, "slots per workgroup");
-    __shared__ __attribute__((aligned(16))) _Float16 act[NWAVES][2][WACT];   // private activation buffers of the waves
+    // private activation planes of the waves: the one-position forward on 16-row tiles needs 2 x 4,128 B, the others 2 x 7,760 B
+    constexpr int WBUF = (MODE == NETMODE_F32_F16) ? 2 * PLANE16 : 2 * WACT;
+    __shared__ __attribute__((aligned(16))) _Float16 act[NWAVES][WBUF];
     __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
     __shared__ SlotMem smem[TS];
     __shared__ float s_val[TS];
     __shared__ float s_pri[TS * 7];
     __shared__ uint32_t s_stats[N_STATS];
     __shared__ __attribute__((aligned(16))) float s_bias[BIAS_LDS_FLOATS];   // stem + conv biases (when the tower fits)
-    static_assert((sizeof(PathEntry) * MAX_DEPTH + sizeof(Rec) * GROUP) * SPW <= sizeof(_Float16) * WACT, "a wave's path stacks must fit its activation buffer");
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab16[(MODE == NETMODE_F32_F16) ? 64 * TAB16 : 8];   // tap offsets of net_forward_wave16
+    static_assert((sizeof(PathEntry) * MAX_DEPTH + sizeof(Rec) * GROUP) * SPW <= sizeof(_Float16) * WBUF, "a wave's path stacks must fit its activation planes");
     const int slot0 = blockIdx.x * TS;
     const int wv = threadIdx.x >> 6;
     // ---- launch prologue: slot states, pending answers and the MLP tables, global -> LDS
@@ -1370,11 +1373,12 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
     }
     for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
     stage_bias_lds(nd, s_bias);
+    if (MODE == NETMODE_F32_F16 && threadIdx.x < 64) build_tab16(s_tab16, threadIdx.x);
     __syncthreads();
     // (a tree call ends when a slot of the wave blocks; max_inner bounds it)
     // the wave's path stacks and hot sibling blocks alias its first activation buffer (dead while the tree runs)
-    PathEntry (*s_path)[MAX_DEPTH] = reinterpret_cast<PathEntry (*)[MAX_DEPTH]>(&act[wv][0][0]);
-    Rec (*s_l1)[GROUP] = reinterpret_cast<Rec (*)[GROUP]>(&act[wv][0][0] + sizeof(PathEntry) * MAX_DEPTH * SPW / sizeof(_Float16));
+    PathEntry (*s_path)[MAX_DEPTH] = reinterpret_cast<PathEntry (*)[MAX_DEPTH]>(&act[wv][0]);
+    Rec (*s_l1)[GROUP] = reinterpret_cast<Rec (*)[GROUP]>(&act[wv][0] + sizeof(PathEntry) * MAX_DEPTH * SPW / sizeof(_Float16));
     unsigned long long t_tree = 0, t_net = 0, n_pass = 0;   // diagnostic (C4_TREE_STAMPS=1)
     // A launch is a time quantum, not a number of rounds: every wave keeps alternating tree work and
     // network passes until n_steps * time_budget cycles have passed, so all waves of the launch end
@@ -1402,21 +1406,19 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
             const int has = __builtin_amdgcn_readfirstlane(smem[sq].has_leaf() ? 1 : 0);
             if (has) pend_slot[cnt++] = sq;
         }
-        if (MODE != NETMODE_F32_2POS) {   // reference-precision net or 64 filters: one position per pass
+        if (MODE == NETMODE_F32_F16) {   // 32 filters, fp16: one position per pass on 16-row MFMA tiles
             for (int i = 0; i < cnt; ++i) {
                 const int sa = pend_slot[i];
-                net_forward_wave1_mode<MODE>(nd, &act[wv][0][0], mlp, s_bias, smem[sa].leaf0, smem[sa].leaf1, s_val, s_pri, sa);
+                net_forward_wave16(nd, &act[wv][0], mlp, s_bias, s_tab16, smem[sa].leaf0, smem[sa].leaf1, s_val, s_pri, sa);
             }
-        } else {
-            for (int i = 0; i < cnt; i += WP) {
-                const int sa = pend_slot[i], sb = pend_slot[i + 1 < cnt ? i + 1 : i];
-                net_forward_wave(nd, &act[wv][0][0], &act[wv][1][0], mlp, s_bias, smem[sa].leaf0, smem[sa].leaf1, smem[sb].leaf0,
-                                 smem[sb].leaf1, min(WP, cnt - i), s_val, s_pri, sa, sb,
-                                 (C4_FUSED_NET_STAMPS && d.has_stamps && blockIdx.x < 16) ? d.cold->stamps + 2048 + (blockIdx.x * NWAVES + wv) * 16 : nullptr);
+        } else {   // reference-precision net or 64 filters: one position per pass on 32-row tiles
+            for (int i = 0; i < cnt; ++i) {
+                const int sa = pend_slot[i];
+                net_forward_wave1_mode<MODE>(nd, &act[wv][0], mlp, s_bias, smem[sa].leaf0, smem[sa].leaf1, s_val, s_pri, sa);
             }
         }
         lds_fence();   // answers (LDS) before the next tree_step reads them
-        if (d.has_stamps) { t_tree += tb - ta; t_net += __builtin_amdgcn_s_memtime() - tb; n_pass += MODE != NETMODE_F32_2POS ? cnt : (cnt + WP - 1) / WP; }
+        if (d.has_stamps) { t_tree += tb - ta; t_net += __builtin_amdgcn_s_memtime() - tb; n_pass += cnt; }
     }
     if (d.has_stamps && blockIdx.x < 128 && (threadIdx.x & 63) == 0) {   // per wave: tree cycles, net cycles | passes << 48
         d.cold->stamps[blockIdx.x * 16 + wv] = t_tree;
@@ -2094,9 +2096,9 @@ int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *prior
     } while (0)
         if (nd.mode == c4net::NETMODE_F64) C4_LAUNCH_WAVE(c4net::NETMODE_F64);
         else if (nd.mode == c4net::NETMODE_F32_PRECISE) C4_LAUNCH_WAVE(c4net::NETMODE_F32_PRECISE);
-        else C4_LAUNCH_WAVE(c4net::NETMODE_F32_2POS);
+        else C4_LAUNCH_WAVE(c4net::NETMODE_F32_F16);
 #undef C4_LAUNCH_WAVE
-    } else if (nd.mode != c4net::NETMODE_F32_2POS) {
+    } else if (nd.mode != c4net::NETMODE_F32_F16) {
         set_err(e->err, "C4_FUSED_MODE=block serves only the 32-filter fp16 net; use the default wave-autonomous kernel");
         return C4_ESTATE;
     } else if (e->fused_slots == 32)

@@ -22,10 +22,11 @@
 //   * storage fp16, accumulation fp32 (same 10-bit mantissa as the TF32 path cuDNN uses by default
 //     for the reference's convs on its own GPU); heads and MLPs in fp32 on the VALU.
 //
-// Two forwards share this arithmetic (bit-identical answers): net_forward_block (above; c4_net_forward,
-// the workgroup-synchronous self-play kernel) and net_forward_wave (one wave = two positions, private
-// LDS buffers, weights streamed from L2 into registers, no workgroup barrier; c4_net_forward_wave and
-// the wave-autonomous self-play kernel).  Both live in c4_net_dev.h.
+// Several forwards share this arithmetic (bit-identical answers): net_forward_block (above; c4_net_forward, the
+// workgroup-synchronous self-play kernel), net_forward_wave16 (one wave = one position on 16-row MFMA tiles,
+// private LDS planes, weights streamed from L2 into registers, no workgroup barrier; c4_net_forward_wave and the
+// wave-autonomous self-play kernel) and net_forward_wave1 (the general one-position form: 64 filters, and the
+// reference-precision mode of the 32-filter net).  All live in c4_net_dev.h.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -52,29 +53,6 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_kernel(NetDev nd, const uint6
     net_forward_block(nd, NetLds{lds, wbuf, mlp}, c0, c1, n, blockIdx.x * P, values, priors);
 }
 
-// Wave-private forward (net_forward_wave) as a kernel of its own: every wave evaluates two positions with
-// no workgroup barrier.  The fused self-play kernel uses the same device function; this entry point
-// exists so that it can be checked and timed in isolation.
-__global__ __launch_bounds__(NTHREADS) void c4_net_wave_kernel(NetDev nd, const uint64_t *__restrict__ c0,
-                                                               const uint64_t *__restrict__ c1, int n,
-                                                               float *__restrict__ values, float *__restrict__ priors,
-                                                               int active_waves, int pos_per_wave)
-{
-    __shared__ __attribute__((aligned(16))) _Float16 act[NWAVES][2][WACT];
-    __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
-    __shared__ __attribute__((aligned(16))) float s_bias[BIAS_LDS_FLOATS];
-    for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
-    stage_bias_lds(nd, s_bias);
-    __syncthreads();
-    const int wv = threadIdx.x >> 6;
-    const int pA = (blockIdx.x * NWAVES + wv) * WP, pB = pA + 1;
-    if (pA >= n) return;
-    if (wv >= active_waves) return;                       // diagnostic (C4_NET_WAVE_ACTIVE): fewer waves per CU
-    const int npos = (pB < n && pos_per_wave == 2) ? 2 : 1;   // diagnostic (C4_NET_WAVE_POS=1): one-position passes
-    net_forward_wave(nd, &act[wv][0][0], &act[wv][1][0], mlp, s_bias, c0[pA], c1[pA], npos == 2 ? c0[pB] : 0, npos == 2 ? c1[pB] : 0, npos,
-                     values, priors, pA, pB, (nd.stamps && blockIdx.x == 0) ? nd.stamps + wv * 16 : nullptr);
-}
-
 // One-position wave-private forward (net_forward_wave1: reference precision at 32 filters, fp16 at 64 filters): one
 // position per wave.  Both c4_net_forward and c4_net_forward_wave run this kernel for such a net (one
 // implementation, so the two entry points and the fused self-play kernel cannot disagree).
@@ -94,6 +72,28 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_wave1_kernel(NetDev nd, const
     if (p >= n) return;
     net_forward_wave1_mode<MODE>(nd, &act[wv][0][0], mlp, s_bias, c0[p], c1[p], values, priors, p,
                                  (nd.stamps && blockIdx.x == 0) ? nd.stamps + wv * 16 : nullptr);
+}
+
+// net_forward_wave16 as a kernel of its own (what c4_net_forward_wave runs for the 32-filter fp16 net): one
+// position per wave, 16-row MFMA tiles -- the very function the self-play kernel evaluates its leaves with.
+__global__ __launch_bounds__(NTHREADS) void c4_net_wave16_kernel(NetDev nd, const uint64_t *__restrict__ c0,
+                                                                 const uint64_t *__restrict__ c1, int n,
+                                                                 float *__restrict__ values, float *__restrict__ priors, int active_waves)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 act[NWAVES][2][PLANE16];
+    __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
+    __shared__ __attribute__((aligned(16))) float s_bias[BIAS_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab[64 * TAB16];
+    for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
+    stage_bias_lds(nd, s_bias);
+    if (threadIdx.x < 64) build_tab16(s_tab, threadIdx.x);
+    __syncthreads();
+    const int wv = threadIdx.x >> 6;
+    const int p = blockIdx.x * NWAVES + wv;
+    if (p >= n) return;
+    if (wv >= active_waves) return;                       // diagnostic (C4_NET_WAVE_ACTIVE): fewer waves per CU
+    net_forward_wave16(nd, &act[wv][0][0], mlp, s_bias, s_tab, c0[p], c1[p], values, priors, p,
+                       (nd.stamps && blockIdx.x == 0) ? nd.stamps + wv * 16 : nullptr);
 }
 
 thread_local char n_err[512] = "";
@@ -194,6 +194,38 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
                 const int ci = 16 * s + 8 * (l >> 5) + j, co = l & 31;
                 split(co < 3 ? desc->head_w[co * FW + ci] : 0.0f, head[((size_t)s * 64 + l) * 8 + j], head_l[((size_t)s * 64 + l) * 8 + j]);
             }
+    // ---- the same weights in v_mfma_f32_16x16x32_f16 fragment order (net_forward_wave16, 32 filters):
+    //      lane l holds cout 16 ct + (l & 15) and the 8 k's 8 (l >> 4) + j of the k-step
+    std::vector<_Float16> stem16, conv16, head16;
+    if (FW == 32) {
+        stem16.assign((size_t)4 * 64 * 8, (_Float16)0.0f);          // [k-step s][ct]: k = 32 s + 8 g + j = tap*4 + ch
+        conv16.assign((size_t)std::max(1, 2 * R) * 18 * 64 * 8, (_Float16)0.0f);   // [L][tap][ct]: cin = 8 g + j
+        head16.assign((size_t)64 * 8, (_Float16)0.0f);              // couts 0..2, cin = 8 g + j
+        for (int s2 = 0; s2 < 2; ++s2)
+            for (int ct = 0; ct < 2; ++ct)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = 32 * s2 + 8 * (l >> 4) + j, tap = k >> 2, ch = k & 3, co = 16 * ct + (l & 15);
+                        if (tap < 9 && ch < 3)
+                            stem16[(((size_t)s2 * 2 + ct) * 64 + l) * 8 + j] = (_Float16)desc->stem_w[((co * 3 + ch) * 3 + tap / 3) * 3 + tap % 3];
+                    }
+        for (int L = 0; L < 2 * R; ++L)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int ct = 0; ct < 2; ++ct)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int ci = 8 * (l >> 4) + j, co = 16 * ct + (l & 15);
+                            conv16[((((size_t)L * 9 + tap) * 2 + ct) * 64 + l) * 8 + j] =
+                                (_Float16)desc->conv_w[((((size_t)L * FW + co) * FW + ci) * 3 + tap / 3) * 3 + tap % 3];
+                        }
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int ci = 8 * (l >> 4) + j, co = l & 15;
+                if (co < 3) head16[((size_t)l) * 8 + j] = (_Float16)desc->head_w[co * FW + ci];
+            }
+    } else {
+        stem16.assign(8, (_Float16)0.0f); conv16.assign(8, (_Float16)0.0f); head16.assign(8, (_Float16)0.0f);
+    }
     std::vector<float> stem_b(desc->stem_b, desc->stem_b + FW), conv_b(desc->conv_b, desc->conv_b + (size_t)2 * R * FW),
         head_b(4, 0.0f), mlp((size_t)MLP_F4 * 4, 0.0f);
     for (int i = 0; i < 3; ++i) head_b[i] = desc->head_b[i];
@@ -224,6 +256,7 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
 #define UP32(vec, field) if (r == hipSuccess) r = upload(net, vec, &net->d.field);
     UP16(stem, stem_w) UP16(conv, conv_w) UP16(head, head_w)
     UP16(stem_l, stem_wl) UP16(conv_l, conv_wl) UP16(head_l, head_wl)
+    UP16(stem16, stem_w16) UP16(conv16, conv_w16) UP16(head16, head_w16)
     UP32(stem_b, stem_b) UP32(conv_b, conv_b) UP32(head_b, head_b)
     {
         const float *pm = nullptr;
@@ -243,7 +276,7 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
     net->d.n_res = R;
     net->d.precise = desc->precision == C4_NET_F32X3 ? 1 : 0;
     net->d.filters = FW;
-    net->d.mode = FW == 64 ? NETMODE_F64 : (net->d.precise ? NETMODE_F32_PRECISE : NETMODE_F32_2POS);
+    net->d.mode = FW == 64 ? NETMODE_F64 : (net->d.precise ? NETMODE_F32_PRECISE : NETMODE_F32_F16);
     if (getenv("C4_NET_STAMPS")) {
         void *q = nullptr;
         if (hipMalloc(&q, 8 * 16 * sizeof(unsigned long long)) == hipSuccess) {
@@ -273,7 +306,7 @@ int c4_net_forward(c4_net *net, void *hip_stream, const uint64_t *color0_dev, co
         return C4_EINVAL;
     }
     if (n == 0) return C4_OK;
-    if (net->d.mode != NETMODE_F32_2POS) return c4_net_forward_wave(net, hip_stream, color0_dev, color1_dev, n, values_dev, priors_dev);
+    if (net->d.mode != NETMODE_F32_F16) return c4_net_forward_wave(net, hip_stream, color0_dev, color1_dev, n, values_dev, priors_dev);
     const dim3 grid((n + P - 1) / P), block(NTHREADS);
     hipLaunchKernelGGL(c4_net_kernel, grid, block, 0, (hipStream_t)hip_stream, net->d, color0_dev, color1_dev, (int)n,
                        values_dev, priors_dev);
@@ -285,7 +318,7 @@ int c4_net_forward(c4_net *net, void *hip_stream, const uint64_t *color0_dev, co
     return C4_OK;
 }
 
-/* Same contract as c4_net_forward, evaluated by the wave-private forward (two positions per wave, no
+/* Same contract as c4_net_forward, evaluated by the wave-private forward (one position per wave, no
  * workgroup barrier; bit-identical answers). */
 int c4_net_forward_wave(c4_net *net, void *hip_stream, const uint64_t *color0_dev, const uint64_t *color1_dev, int32_t n,
                         float *values_dev, float *priors_dev)
@@ -295,7 +328,7 @@ int c4_net_forward_wave(c4_net *net, void *hip_stream, const uint64_t *color0_de
         return C4_EINVAL;
     }
     if (n == 0) return C4_OK;
-    if (net->d.mode != NETMODE_F32_2POS) {
+    if (net->d.mode != NETMODE_F32_F16) {
         const dim3 g1((n + NWAVES - 1) / NWAVES), b1(NTHREADS);
         if (net->d.mode == NETMODE_F64)
             hipLaunchKernelGGL(c4_net_wave1_kernel<NETMODE_F64>, g1, b1, 0, (hipStream_t)hip_stream, net->d, color0_dev, color1_dev, (int)n, values_dev, priors_dev);
@@ -308,14 +341,12 @@ int c4_net_forward_wave(c4_net *net, void *hip_stream, const uint64_t *color0_de
         }
         return C4_OK;
     }
-    const int per_block = NWAVES * WP;
-    const dim3 grid((n + per_block - 1) / per_block), block(NTHREADS);
-    const char *ea = getenv("C4_NET_WAVE_ACTIVE"), *ep = getenv("C4_NET_WAVE_POS");   // timing experiments only
-    hipLaunchKernelGGL(c4_net_wave_kernel, grid, block, 0, (hipStream_t)hip_stream, net->d, color0_dev, color1_dev, (int)n,
-                       values_dev, priors_dev, ea ? atoi(ea) : NWAVES, ep ? atoi(ep) : WP);
+    const char *ea16 = getenv("C4_NET_WAVE_ACTIVE");   // timing experiments only: fewer waves per CU
+    hipLaunchKernelGGL(c4_net_wave16_kernel, dim3((n + NWAVES - 1) / NWAVES), dim3(NTHREADS), 0, (hipStream_t)hip_stream, net->d,
+                       color0_dev, color1_dev, (int)n, values_dev, priors_dev, ea16 ? atoi(ea16) : NWAVES);
     hipError_t r = hipGetLastError();
     if (r != hipSuccess) {
-        snprintf(n_err, 512, "c4_net_wave_kernel launch failed: %s", hipGetErrorString(r));
+        snprintf(n_err, 512, "c4_net_wave16_kernel launch failed: %s", hipGetErrorString(r));
         return C4_EDEVICE;
     }
     return C4_OK;

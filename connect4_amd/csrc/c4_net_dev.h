@@ -7,10 +7,6 @@
 #include <cstdint>
 #include <vector>
 
-#ifndef C4_BF_AHEAD
-#define C4_BF_AHEAD 1   // k-steps the wave-private forward reads its activation fragments ahead (tuning aid)
-#endif
-
 namespace c4net {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -49,6 +45,8 @@ struct NetDev {
     int precise;
     int filters;           // 32 or 64
     int mode;              // NETMODE_* the kernels are specialised for
+    // 32 filters, fp16: the same weights in the fragment order of v_mfma_f32_16x16x32_f16 (net_forward_wave16)
+    const half8 *stem_w16, *conv_w16, *head_w16;
     unsigned long long *stamps;   // diagnostic only (C4_NET_STAMPS=1): [wave][16] s_memtime values of block 0
 };
 
@@ -124,7 +122,7 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
                                                   float *__restrict__ values, float *__restrict__ priors,
                                                   const int *out_map = nullptr)
 {
-    // laundered thread id (see net_forward_wave_nt): keeps this function's lane-derived addresses from being
+    // laundered thread id: keeps this function's lane-derived addresses from being
     // hoisted out of a persistent caller's step loop and spilled across its tree phase
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -416,273 +414,25 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
 
 
 // ------------------------------------------------------------------------------------------------
-// Wave-private forward: ONE wave evaluates up to WP = 2 positions (84 rows = 3 MFMA tiles) with no
-// workgroup barrier at all -- the fused self-play kernel lets every wave evaluate the leaves of its own
-// trees the moment they are needed instead of waiting for the slowest tree of the workgroup.
-//   * activations ping-pong between two private LDS buffers of (96 + 1 zero) rows x 40 halves;
-//   * the layer's 18 A fragments (weights) live in 72 VGPRs and come straight from global memory (the
-//     whole net is ~110 KB, L2 resident): fragment s of layer L+1 is requested into the same
-//     registers right after its last use in layer L, so the refill hides under a whole layer;
-//   * k-step outer, tile inner: three independent MFMAs back to back per k-step;
-//   * per-element arithmetic (bias as the accumulator's initial value, k order, identity-MFMA skip,
-//     epilogue, heads, MLPs) is the same as net_forward_block's, so both give bit-identical answers.
+// Wave-private forwards: ONE wave evaluates ONE position with no workgroup barrier at all -- the fused
+// self-play kernel lets every wave evaluate the leaves of its own trees the moment they are needed instead
+// of waiting for the slowest tree of the workgroup.  Activations ping-pong between private LDS planes of
+// 43 rows (42 pixels + the zero row that out-of-board taps read instead of branching); the weights stream
+// from L2 (the whole net is ~110 KB) into registers ahead of their use; per-element arithmetic (bias as the
+// accumulator's initial value, k order, identity-MFMA skip, epilogue, heads, MLPs) is net_forward_block's,
+// so all forwards of one net give bit-identical answers (tests/test_gpu_fused_net.py).
+//   net_forward_wave16          32 filters, fp16 storage: the self-play kernel's hot forward (16-row MFMA tiles)
+//   net_forward_wave1<FW, P>    general form on 32-row tiles: 64 filters, and reference precision at 32 filters
+// (Rounds 1-2 also had a two-position forward on 32-row tiles, 34 k cycles per pass against 27 k for one
+// position; inside the fused kernel almost every pass has ONE leaf, and a second row cost ~1.5x there.)
 // ------------------------------------------------------------------------------------------------
-constexpr int WP = 2;                        // positions per pass
-constexpr int WTILES = 3;
-constexpr int WROWS = WTILES * 32;           // 96 rows, 84 of them real for two positions
-constexpr int WACT = (WROWS + 1) * CS;       // halves per private activation buffer (7,760 B)
-
-// NT: tiles that hold real rows, 2 (one position) or 3 (two positions).
-template <int NT>
-__device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *a0, _Float16 *a1, const float4 *mlp,
-                                                    const float *bias_lds, uint64_t bA0, uint64_t bA1, uint64_t bB0, uint64_t bB1,
-                                                    int npos, float *__restrict__ values, float *__restrict__ priors, int outA,
-                                                    int outB, unsigned long long *stamps = nullptr)
-{
-    // The lane id is laundered once per pass: inside a persistent kernel the compiler would otherwise hoist
-    // every lane-derived address of this function out of the caller's step loop, keep ~25 of them live
-    // across the tree walk and reload them from scratch (each reload drains vmcnt) in the middle of the pass.
-    int lane_ = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane_));
-    const int lane = lane_;
-    const int r32 = lane & 31, h = lane >> 5;
-    const int nreal = npos * PIX;
-    auto stamp = [&](int i) { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); };   // diagnostic (C4_NET_STAMPS=1)
-    stamp(0);
-    const int n_layers = 2 * nd.n_res;
-    // this lane's 16 output channels are {8q + 4h + 0..3 : q = 0..3}
-    auto load_bias = [&](const float *b, float4 (&out)[4]) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) out[q] = *reinterpret_cast<const float4 *>(b + 8 * q + 4 * h);
-    };
-    // everything that comes from global memory is requested up front / a layer ahead
-    half8 w[KSTEPS];
-    if (n_layers > 0) {
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) w[s] = nd.conv_w[s * 64 + lane];
-    }
-    half8 sw[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) sw[s] = nd.stem_w[s * 64 + lane];
-    // biases come from the caller's LDS copy (stem at 0, conv layer L at 32 * (1 + L)): four ds_read_b128
-    // at the start of a layer instead of 16 VGPRs of global prefetch held across the layer before
-    float4 bias[4];
-    load_bias(bias_lds, bias);
-    // input planes (board.py:147-154), 4 halves per row, in a1 (the tower writes a1 only after the stem)
-    _Float16 *inp = a1;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = lane + 64 * i;
-        if (r <= WROWS) {
-            half4 v = {};
-            if (r < nreal) {
-                const int p = r >= PIX ? 1 : 0, pix = r - p * PIX;
-                const int y = pix / 7, x = pix - y * 7;
-                const uint64_t b0 = p ? bB0 : bA0, b1 = p ? bB1 : bA1;
-                const int bit = x * 7 + (5 - y);
-                v[0] = (_Float16)((__popcll(b0 | b1) & 1) ? 0.0f : 1.0f);
-                v[1] = (_Float16)(float)((b0 >> bit) & 1);
-                v[2] = (_Float16)(float)((b1 >> bit) & 1);
-            }
-            *reinterpret_cast<half4 *>(inp + r * 4) = v;   // r == WROWS: the zero row of the planes
-        }
-    }
-    if (lane < CS) { a0[WROWS * CS + lane] = (_Float16)0.0f; a1[WROWS * CS + lane] = (_Float16)0.0f; }
-
-    // row geometry of the wave's tiles; rows that hold no real pixel read the zero row only
-    // tap offsets (in halves, < 2^16) packed two per register: taps 2j and 2j+1 share rsel2[ti][j]
-    uint32_t rsel2[NT][5];
-    int rbase[NT];
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti) {
-        const int rg = ti * 32 + r32;
-        const int p = rg >= PIX ? 1 : 0, pix = rg - p * PIX;
-        const int y = pix / 7, x = pix - y * 7;
-        const bool real = rg < nreal;
-        rbase[ti] = rg * CS;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) rsel2[ti][j] = 0;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            const int ok = -(int)(real && (unsigned)(y + dy) < 6u && (unsigned)(x + dx) < 7u);
-            const uint32_t off = (uint32_t)((((rg + dy * 7 + dx) & ok) | (WROWS & ~ok)) * CS + 8 * h);
-            rsel2[ti][tap >> 1] |= off << (16 * (tap & 1));
-        }
-    }
-    auto rsel = [&](int ti, int tap) -> int { return (int)((rsel2[ti][tap >> 1] >> (16 * (tap & 1))) & 0xffffu); };
-    // ------------------------------------------------------------------ stem: planes -> a0
-    {
-        floatx16 acc[NT];
-        half4 v[NT][6];
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti) {
-            const int rg = ti * 32 + r32;
-            const int p = rg >= PIX ? 1 : 0, pix = rg - p * PIX;
-            const int y = pix / 7, x = pix - y * 7;
-            const bool real = rg < nreal;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int tap = 4 * (i >> 1) + 2 * h + (i & 1);      // k = 16s + 8h + j = tap*4 + channel
-                const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;   // tap/3, tap%3 for tap < 12
-                const int ok = -(int)(real && tap < 9 && (unsigned)(y + ty - 1) < 6u && (unsigned)(x + tx - 1) < 7u);
-                const int row = ((rg + (ty - 1) * 7 + tx - 1) & ok) | (WROWS & ~ok);
-                v[ti][i] = *reinterpret_cast<const half4 *>(inp + row * 4);
-            }
-            acc[ti] = acc_from_bias(bias);
-        }
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-            for (int ti = 0; ti < NT; ++ti) {
-                half8 bf;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { bf[j] = v[ti][2 * s][j]; bf[4 + j] = v[ti][2 * s + 1][j]; }
-                acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sw[s], bf, acc[ti], 0, 0, 0);
-            }
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti) store_tile(acc[ti], a0, rbase[ti], h);
-    }
-    stamp(1);
-
-    // ------------------------------------------------------------------ residual tower
-    for (int L = 0; L < n_layers; ++L) {
-        const _Float16 *src = (L & 1) ? a1 : a0;
-        _Float16 *dst = (L & 1) ? a0 : a1;
-        const bool second = L & 1;   // conv2 of a block: add the block input (lives in dst) and overwrite it
-        floatx16 acc[NT];
-        load_bias(bias_lds + F * (1 + L), bias);
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti) acc[ti] = acc_from_bias(bias);
-        // the refill is unconditional (the last layer re-requests layer 0): a branch around the loads
-        // makes the compiler drain vmcnt in front of each of them
-        const int Ln = L + 1 < n_layers ? L + 1 : 0;
-        const half8 *wnext = nd.conv_w + (size_t)Ln * WCHUNKS + lane;
-        // B fragments (activations) are read from LDS C4_BF_AHEAD k-steps ahead of the MFMAs that consume them
-        // (ring of C4_BF_AHEAD + 1 fragment sets; all indices are compile-time after unrolling)
-        constexpr int PD = C4_BF_AHEAD;
-        half8 bq[PD + 1][NT];
-#pragma unroll
-        for (int a = 0; a < PD; ++a)
-#pragma unroll
-            for (int ti = 0; ti < NT; ++ti) bq[a][ti] = *reinterpret_cast<const half8 *>(src + rsel(ti, a >> 1) + (a & 1) * 16);
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            if (s + PD < KSTEPS) {
-#pragma unroll
-                for (int ti = 0; ti < NT; ++ti)
-                    bq[(s + PD) % (PD + 1)][ti] = *reinterpret_cast<const half8 *>(src + rsel(ti, (s + PD) >> 1) + ((s + PD) & 1) * 16);
-            }
-#pragma unroll
-            for (int ti = 0; ti < NT; ++ti) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s], bq[s % (PD + 1)][ti], acc[ti], 0, 0, 0);
-            w[s] = wnext[s * 64];   // fragment s of the next layer, a whole layer ahead of its use
-        }
-        if (L == 2) stamp(12);
-        if (second) {
-            half8 idf[2];   // identity A fragments: skip[cout][row] = sum_k I[cout][k] * x[k][row] (built where used)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) idf[s][j] = (_Float16)((16 * s + 8 * h + j) == r32 ? 1.0f : 0.0f);
-#pragma unroll
-            for (int ti = 0; ti < NT; ++ti) {
-                const half8 x0 = *reinterpret_cast<const half8 *>(dst + rbase[ti] + 8 * h);
-                const half8 x1 = *reinterpret_cast<const half8 *>(dst + rbase[ti] + 16 + 8 * h);
-                acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[0], x0, acc[ti], 0, 0, 0);
-                acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[1], x1, acc[ti], 0, 0, 0);
-            }
-        }
-        if (L == 2) stamp(13);
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti) store_tile(acc[ti], dst, rbase[ti], h);
-        if (L == 2) stamp(14);
-        if (L < 6) stamp(2 + L);
-    }
-    // tower output is in a0 (n_layers is even)
-    stamp(8);
-
-    // ------------------------------------------------------------------ 1x1 head convs (value + 2 policy channels)
-    float *hs = reinterpret_cast<float *>(a1);   // [WP][HSTR] fp32: value plane 0..41, policy planes 42..125
-    const half8 hw0 = nd.head_w[lane], hw1 = nd.head_w[64 + lane];
-    const float hb0 = nd.head_b[0], hb1 = nd.head_b[1], hb2 = nd.head_b[2];
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti) {
-        const int rg = ti * 32 + r32;
-        const int p = rg >= PIX ? 1 : 0, pix = rg - p * PIX;
-        const half8 x0 = *reinterpret_cast<const half8 *>(a0 + rbase[ti] + 8 * h);
-        const half8 x1 = *reinterpret_cast<const half8 *>(a0 + rbase[ti] + 16 + 8 * h);
-        floatx16 acc = {};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hw0, x0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hw1, x1, acc, 0, 0, 0);
-        if (h == 0 && rg < WP * PIX) {   // couts 0..3 sit in registers 0..3 of the lower half-wave
-            hs[p * HSTR + 0 * PIX + pix] = lrelu(acc[0] + hb0);
-            hs[p * HSTR + 1 * PIX + pix] = lrelu(acc[1] + hb1);
-            hs[p * HSTR + 2 * PIX + pix] = lrelu(acc[2] + hb2);
-        }
-    }
-    if (lane < 2 * WP) hs[(lane >> 1) * HSTR + HEADV + (lane & 1)] = 0.0f;   // pad 126,127
-    stamp(9);
-    // ------------------------------------------------------------------ MLP heads (fp32 VALU), as in net_forward_block
-    {
-        const float *vt_b = reinterpret_cast<const float *>(mlp + VT_F4 + PT_F / 4);   // fc_b | vout_w | pfc_b
-        const float *pt = reinterpret_cast<const float *>(mlp + VT_F4);
-        const float4 *hA4 = reinterpret_cast<const float4 *>(hs);
-        const float4 *hB4 = reinterpret_cast<const float4 *>(hs + HSTR);
-        float v0 = 0.0f, v1 = 0.0f;
-#pragma unroll
-        for (int g = 0; g < 11; ++g) {
-            const float4 wv = mlp[g * 64 + lane];
-            const float4 xa = hA4[g];
-            v0 += wv.x * xa.x + wv.y * xa.y + wv.z * xa.z + wv.w * xa.w;
-            if (NT == 3) {
-                const float4 xb = hB4[g];
-                v1 += wv.x * xb.x + wv.y * xb.y + wv.z * xb.z + wv.w * xb.w;
-            }
-        }
-        const int seg = lane >> 3;
-        const float *hpA = hs + PIX + seg * 11, *hpB = hs + HSTR + PIX + seg * 11;
-        float l0 = 0.0f, l1 = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 11; ++c) {
-            const float wv = pt[c * 64 + lane];      // zero where seg*11 + c >= 84 or (lane & 7) == 7
-            const int cc = seg * 11 + c < 2 * PIX ? c : 2 * PIX - 1 - seg * 11;
-            l0 += wv * hpA[cc];
-            if (NT == 3) l1 += wv * hpB[cc];
-        }
-        l0 += dppf<0x128>(l0);
-        if (NT == 3) l1 += dppf<0x128>(l1);
-#pragma unroll
-        for (int m = 16; m <= 32; m <<= 1) {
-            l0 += __shfl_xor(l0, m, 64);
-            if (NT == 3) l1 += __shfl_xor(l1, m, 64);
-        }
-        const float fb = vt_b[lane], vw = vt_b[64 + lane], pb = vt_b[128 + lane];
-        const bool is_pol = lane < 7;
-#pragma unroll
-        for (int pp = 0; pp < (NT == 3 ? 2 : 1); ++pp) {
-            const float a = (pp ? v1 : v0) + fb;
-            const float lg = (pp ? l1 : l0) + pb;
-            const int go = pp ? outB : outA;
-            const float rs = sum16(lane < PIX ? vw * lrelu(a) : 0.0f);               // model.py:83-85
-            const float vsum = readlane_f(rs, 0) + readlane_f(rs, 16) + readlane_f(rs, 32);
-            const float value = (tanhf(vsum + nd.vout_b) + nd.w1) * nd.w2;           // model.py:86-88
-            const float mx = max8(is_pol ? lg : -INFINITY);
-            const float e = is_pol ? expf(lg - mx) : 0.0f;
-            const float sum = sum8(e);
-            if (pp < npos) {
-                if (lane == 0) values[go] = value;
-                if (is_pol) priors[(size_t)go * 7 + lane] = e / sum;
-            }
-        }
-    }
-    stamp(10);
-}
+constexpr int WACT = (96 + 1) * CS;          // halves of one of a wave's two private buffers as the general forward sizes them (7,760 B)
 
 // ------------------------------------------------------------------------------------------------
 // One-position wave-private forward, net_forward_wave1<FW, PRECISE>: the general form of the wave-private
 // forward -- any supported width FW (32 or 64 filters = 1 or 2 cout blocks of 32 per MFMA), optionally in
-// reference precision -- for ONE position per pass.  (net_forward_wave above is the tuned special case
-// FW = 32, fp16 storage, two positions per pass.)
+// reference precision -- for ONE position per pass.  (net_forward_wave16 below is the tuned special case
+// FW = 32, fp16 storage, on 16-row tiles.)
 //
 // PRECISE (C4_NET_F32X3): every fp32 operand x (folded weight, activation) is carried as two fp16 numbers
 //     x  ~=  hi + lo / 2^11,      hi = f16(x),   lo = f16((x - hi) * 2^11)
@@ -698,7 +448,7 @@ __device__ __forceinline__ void net_forward_wave_nt(const NetDev &nd, _Float16 *
 //     (2 x 6,192 B); <64, precise> does not fit and is not offered;
 //   * weights: fragments stream from L2 through a rolling window of WDEPTH k-steps (the tower's k-steps are
 //     one linear sequence in memory, so the window rolls across layer boundaries);
-//   * heads and MLPs as in net_forward_wave (fp32 VALU), fed with the folded fp32 activations.
+//   * heads and MLPs as in net_forward_block (fp32 VALU), fed with the folded fp32 activations.
 // ------------------------------------------------------------------------------------------------
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
 constexpr int PROWS = PIX + 1;               // 42 real rows + the zero row
@@ -744,7 +494,7 @@ __device__ __forceinline__ void net_forward_wave1(const NetDev &nd, _Float16 *bu
     static_assert(wave1_supported(FW, PRECISE), "this width / precision does not fit the wave's private LDS");
     static_assert((PRECISE ? 4 : 2) * PLANE <= 2 * WACT, "planes must fit the wave's two private buffers");
     int lane_ = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane_));     // see net_forward_wave_nt: keep lane-derived addresses out of the caller's loop
+    asm volatile("" : "+v"(lane_));     // inside a persistent kernel the compiler would otherwise hoist every lane-derived address of this function out of the caller's step loop, keep them live across the tree walk and reload them from scratch mid-pass
     const int lane = lane_;
     const int r32 = lane & 31, h = lane >> 5;
     auto stamp = [&](int i) { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); };
@@ -980,7 +730,7 @@ __device__ __forceinline__ void net_forward_wave1(const NetDev &nd, _Float16 *bu
         if (lane < 2) hs[HEADV + lane] = 0.0f;   // pad 126,127
     }
     stamp(9);
-    // ------------------------------------------------------------------ MLP heads (fp32 VALU), as in net_forward_wave
+    // ------------------------------------------------------------------ MLP heads (fp32 VALU), as in net_forward_block
     {
         const float *vt_b = reinterpret_cast<const float *>(mlp + VT_F4 + PT_F / 4);   // fc_b | vout_w | pfc_b
         const float *pt = reinterpret_cast<const float *>(mlp + VT_F4);
@@ -1020,8 +770,271 @@ __device__ __forceinline__ void net_forward_wave1(const NetDev &nd, _Float16 *bu
     stamp(10);
 }
 
+// ------------------------------------------------------------------------------------------------
+// net_forward_wave16: the one-position wave-private forward of the 32-filter fp16 net on 16-row MFMA
+// tiles (v_mfma_f32_16x16x32_f16): the position's 42 pixels take 3 row tiles (48 rows) instead of two
+// 32-row tiles (64 rows), a k-step is one whole tap (K = 32 input channels), so a 3x3 layer is
+// 9 taps x 3 row tiles x 2 cout tiles = 54 MFMAs of 16 cycles (864 cycles) instead of 36 of 32 (1152), and
+// the epilogue handles 24 values per lane instead of 32.  This is the forward the wave-autonomous
+// self-play kernel spends ~40 % of its time in, almost always with ONE leaf to evaluate.
+//   * operands: A[cout l&15 (+16 ct)][cin 8(l>>4)+j] = weights (host order stem_w16 / conv_w16 / head_w16),
+//     B[cin 8(l>>4)+j][pixel l&15] = one 16-byte LDS read of the tap-shifted row; C: lane holds 4 consecutive
+//     couts 16 ct + 4(l>>4) + i of pixel l&15 -> one 8-byte LDS store per tile;
+//   * planes of 43 rows (42 pixels + the zero row out-of-board taps read) x 48 halves: the 96-byte row stride
+//     makes the B reads bank-conflict free in ds_read_b128's 16-lane groups (80 bytes is 2-way here);
+//   * tap offsets come from a 5 KB LDS table built once per launch (the geometry depends on the lane only):
+//     five ds_read_b128 per pass instead of ~200 integer instructions;
+//   * bias = the accumulators' initial value, read from LDS straight in accumulator order; residual skip =
+//     one identity MFMA per tile; weights of a layer in 72 VGPRs: fragment i of layer L+1 is requested into the same
+//     registers right after its last use in layer L, so the refill hides under a whole layer.
+// One 16x16x32 step accumulates exactly like two 32x32x16 steps over the same 32 channels: the answers are
+// bit-identical to net_forward_block's (measured on MI355X over thousands of positions and two tower depths,
+// asserted by tests/test_gpu_fused_net.py::test_wave_private_forward_is_bit_identical).
+// ------------------------------------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int CS16 = 48;                       // halves per LDS row: 96-byte stride
+constexpr int PLANE16 = PROWS * CS16;          // halves per plane (4,128 B)
+constexpr int RT16 = 3;                        // row tiles of 16
+constexpr int TAB16 = 40;                      // u16 per lane in the tap-offset table: 27 tower taps + 12 stem taps + pad
+static_assert(2 * PLANE16 <= 2 * WACT, "the two planes must fit the wave's private buffers");
+
+// tap-offset table, one row of TAB16 u16 per lane id (built once per launch by 64 threads of the workgroup):
+//   [rt*9 + tap]            offset in halves of (pixel row 16 rt + (l&15), tap) in a plane, + 8 (l>>4); the zero row
+//                           where the pixel is not real or the tap leaves the board
+//   [27 + rt*4 + s*2 + e]   stem: offset in halves (4 per row) of input-plane row for tap 8 s + 2 (l>>4) + e
+__device__ __forceinline__ void build_tab16(uint16_t *tab, int lane)
+{
+    const int n = lane & 15, g = lane >> 4;
+    for (int rt = 0; rt < RT16; ++rt) {
+        const int r = 16 * rt + n, y = r / 7, x = r - 7 * y;
+        const bool real = r < PIX;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const bool ok = real && (unsigned)(y + dy) < 6u && (unsigned)(x + dx) < 7u;
+            tab[lane * TAB16 + rt * 9 + tap] = (uint16_t)((ok ? r + 7 * dy + dx : PIX) * CS16 + 8 * g);
+        }
+        for (int s = 0; s < 2; ++s)
+            for (int e = 0; e < 2; ++e) {
+                const int tap = 8 * s + 2 * g + e;
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                const bool ok = real && tap < 9 && (unsigned)(y + dy) < 6u && (unsigned)(x + dx) < 7u;
+                tab[lane * TAB16 + 27 + rt * 4 + s * 2 + e] = (uint16_t)((ok ? r + 7 * dy + dx : PIX) * 4);
+            }
+    }
+    tab[lane * TAB16 + 39] = 0;
+}
+
+__device__ __forceinline__ void store16(const floatx4 &acc, _Float16 *dst, int off, bool real)
+{
+    half4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (_Float16)lrelu(acc[i]);
+    if (real) *reinterpret_cast<half4 *>(dst + off) = o;
+}
+
+__device__ __forceinline__ void net_forward_wave16(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds,
+                                                   const uint16_t *tab, uint64_t b0, uint64_t b1, float *__restrict__ values,
+                                                   float *__restrict__ priors, int out, unsigned long long *stamps = nullptr)
+{
+    int lane_ = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_));     // inside a persistent kernel the compiler would otherwise hoist every lane-derived address of this function out of the caller's step loop, keep them live across the tree walk and reload them from scratch mid-pass
+    const int lane = lane_;
+    const int n = lane & 15, g = lane >> 4;
+    auto stamp = [&](int i) { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
+    const int n_layers = 2 * nd.n_res;
+    _Float16 *const p0 = buf, *const p1 = buf + PLANE16;
+    // weights: the layer's 18 fragments (tap t, cout tile ct) at [(L*9 + t)*2 + ct][64 lanes], a layer ahead
+    half8 w[18];
+    if (n_layers > 0) {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) w[i] = nd.conv_w16[i * 64 + lane];
+    }
+    half8 sw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sw[i] = nd.stem_w16[i * 64 + lane];
+    // tap offsets of this lane
+    uint32_t tb[TAB16 / 2];
+    {
+        const uint4 *t4 = reinterpret_cast<const uint4 *>(tab + lane * TAB16);
+#pragma unroll
+        for (int i = 0; i < TAB16 / 8; ++i) { const uint4 v = t4[i]; tb[4 * i] = v.x; tb[4 * i + 1] = v.y; tb[4 * i + 2] = v.z; tb[4 * i + 3] = v.w; }
+    }
+    auto tof = [&](int idx) -> int { return (int)((tb[idx >> 1] >> (16 * (idx & 1))) & 0xffffu); };
+    // input planes (board.py:147-154), 4 halves per row, at the start of p1 (the tower writes p1 only after the stem)
+    _Float16 *inp = p1;
+    if (lane <= PIX) {
+        half4 v = {};
+        if (lane < PIX) {
+            const int y = lane / 7, x = lane - y * 7;
+            const int bit = x * 7 + (5 - y);
+            v[0] = (_Float16)((__popcll(b0 | b1) & 1) ? 0.0f : 1.0f);
+            v[1] = (_Float16)(float)((b0 >> bit) & 1);
+            v[2] = (_Float16)(float)((b1 >> bit) & 1);
+        }
+        *reinterpret_cast<half4 *>(inp + lane * 4) = v;   // lane == PIX: the zero row of the planes
+    }
+    if (lane < CS16) { p0[PIX * CS16 + lane] = (_Float16)0.0f; p1[PIX * CS16 + lane] = (_Float16)0.0f; }
+    bool real[RT16];
+    int rbase[RT16];
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt) {
+        real[rt] = 16 * rt + n < PIX;
+        rbase[rt] = (real[rt] ? 16 * rt + n : PIX) * CS16;
+    }
+    // this lane's 4 output channels of cout tile ct are 16 ct + 4 g + 0..3: bias in accumulator order
+    auto bias4 = [&](const float *b, int ct) -> floatx4 {
+        const float4 v = *reinterpret_cast<const float4 *>(b + 16 * ct + 4 * g);
+        return floatx4{v.x, v.y, v.z, v.w};
+    };
+    // ------------------------------------------------------------------ stem: planes -> p0   (K = 36 -> two k-steps of 32)
+    {
+        floatx4 acc[RT16][2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const floatx4 bv = bias4(bias_lds, ct);
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) acc[rt][ct] = bv;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) {
+                const half4 va = *reinterpret_cast<const half4 *>(inp + tof(27 + rt * 4 + s * 2));
+                const half4 vb = *reinterpret_cast<const half4 *>(inp + tof(27 + rt * 4 + s * 2 + 1));
+                half8 bf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bf[j] = va[j]; bf[4 + j] = vb[j]; }
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sw[s * 2 + ct], bf, acc[rt][ct], 0, 0, 0);
+            }
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) store16(acc[rt][ct], p0, rbase[rt] + 16 * ct + 4 * g, real[rt]);
+    }
+    stamp(1);
+    // ------------------------------------------------------------------ residual tower
+    for (int L = 0; L < n_layers; ++L) {
+        const bool second = L & 1;
+        const _Float16 *src = second ? p1 : p0;
+        _Float16 *dst = second ? p0 : p1;
+        floatx4 acc[RT16][2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const floatx4 bv = bias4(bias_lds + F * (1 + L), ct);
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) acc[rt][ct] = bv;
+        }
+        const int Ln = L + 1 < n_layers ? L + 1 : 0;       // unconditional refill: a branch around the loads makes the compiler drain vmcnt in front of each
+        const half8 *wnext = nd.conv_w16 + (size_t)Ln * 18 * 64 + lane;
+        half8 bc[RT16], bn[RT16];
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt) bc[rt] = *reinterpret_cast<const half8 *>(src + tof(rt * 9));
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t + 1 < 9) {
+#pragma unroll
+                for (int rt = 0; rt < RT16; ++rt) bn[rt] = *reinterpret_cast<const half8 *>(src + tof(rt * 9 + t + 1));
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+                for (int rt = 0; rt < RT16; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[2 * t + ct], bc[rt], acc[rt][ct], 0, 0, 0);
+                w[2 * t + ct] = wnext[(2 * t + ct) * 64];
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) bc[rt] = bn[rt];
+        }
+        if (L == 2) stamp(12);
+        if (second) {   // + block input (lives in dst): skip[cout][pixel] = sum_k I[cout][k] x[k][pixel]
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) {
+                const half8 x = *reinterpret_cast<const half8 *>(dst + rbase[rt] + 8 * g);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    half8 idf;      // identity fragment of cout tile ct: A[cout n][cin 8g + j] = (8g + j == 16 ct + n)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) idf[j] = (_Float16)((8 * g + j) == 16 * ct + n ? 1.0f : 0.0f);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(idf, x, acc[rt][ct], 0, 0, 0);
+                }
+            }
+        }
+        if (L == 2) stamp(13);
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) store16(acc[rt][ct], dst, rbase[rt] + 16 * ct + 4 * g, real[rt]);
+        if (L == 2) stamp(14);
+        if (L < 6) stamp(2 + L);
+    }
+    stamp(8);
+    // tower output is in p0 (n_layers is even)
+    // ------------------------------------------------------------------ 1x1 head convs: couts 0..2 = rows 0..2 of cout tile 0
+    float *hs = reinterpret_cast<float *>(p1);   // [HSTR] fp32: value plane 0..41, policy planes 42..125 (p1 is free)
+    {
+        const half8 hw = nd.head_w16[lane];
+        const float hb0 = nd.head_b[0], hb1 = nd.head_b[1], hb2 = nd.head_b[2];
+        floatx4 a[RT16];
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt) {
+            const half8 x = *reinterpret_cast<const half8 *>(p0 + rbase[rt] + 8 * g);
+            a[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hw, x, floatx4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt) {
+            const int r = 16 * rt + n;
+            if (g == 0 && r < PIX) {      // couts 0..3 sit in the accumulators of lanes 0..15
+                hs[0 * PIX + r] = lrelu(a[rt][0] + hb0);
+                hs[1 * PIX + r] = lrelu(a[rt][1] + hb1);
+                hs[2 * PIX + r] = lrelu(a[rt][2] + hb2);
+            }
+        }
+        if (lane < 2) hs[HEADV + lane] = 0.0f;   // pad 126,127
+    }
+    stamp(9);
+    // ------------------------------------------------------------------ MLP heads (fp32 VALU), as in net_forward_block
+    {
+        const float *vt_b = reinterpret_cast<const float *>(mlp + VT_F4 + PT_F / 4);   // fc_b | vout_w | pfc_b
+        const float *pt = reinterpret_cast<const float *>(mlp + VT_F4);
+        const float4 *hA4 = reinterpret_cast<const float4 *>(hs);
+        float v0 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 11; ++q) {
+            const float4 wv = mlp[q * 64 + lane];
+            const float4 xa = hA4[q];
+            v0 += wv.x * xa.x + wv.y * xa.y + wv.z * xa.z + wv.w * xa.w;
+        }
+        const int seg = lane >> 3;
+        const float *hpA = hs + PIX + seg * 11;
+        float l0 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 11; ++c) {
+            const float wv = pt[c * 64 + lane];      // zero where seg*11 + c >= 84 or (lane & 7) == 7
+            const int cc = seg * 11 + c < 2 * PIX ? c : 2 * PIX - 1 - seg * 11;
+            l0 += wv * hpA[cc];
+        }
+        l0 += dppf<0x128>(l0);
+#pragma unroll
+        for (int m = 16; m <= 32; m <<= 1) l0 += __shfl_xor(l0, m, 64);
+        const float fb = vt_b[lane], vw = vt_b[64 + lane], pb = vt_b[128 + lane];
+        const bool is_pol = lane < 7;
+        const float a = v0 + fb;
+        const float lg = l0 + pb;
+        const float rs = sum16(lane < PIX ? vw * lrelu(a) : 0.0f);               // model.py:83-85
+        const float vsum = readlane_f(rs, 0) + readlane_f(rs, 16) + readlane_f(rs, 32);
+        const float value = (tanhf(vsum + nd.vout_b) + nd.w1) * nd.w2;           // model.py:86-88
+        const float mx = max8(is_pol ? lg : -INFINITY);
+        const float e = is_pol ? expf(lg - mx) : 0.0f;
+        const float sum = sum8(e);
+        if (lane == 0) values[out] = value;
+        if (is_pol) priors[(size_t)out * 7 + lane] = e / sum;
+    }
+    stamp(10);
+}
+
 // net mode of a NetDev, as the kernels are specialised
-constexpr int NETMODE_F32_2POS = 0;   // 32 filters, fp16 storage: net_forward_wave / net_forward_block (two positions per pass)
+constexpr int NETMODE_F32_F16 = 0;    // 32 filters, fp16 storage: net_forward_wave16 / net_forward_block
 constexpr int NETMODE_F32_PRECISE = 1;
 constexpr int NETMODE_F64 = 2;        // 64 filters, fp16 storage, one position per pass
 template <int MODE>
@@ -1040,15 +1053,6 @@ __device__ __forceinline__ void stage_bias_lds(const NetDev &nd, float *bias_lds
     const int n_layers = 2 * nd.n_res, fw = nd.filters;
     for (int i = threadIdx.x; i < fw * (1 + n_layers); i += NTHREADS) bias_lds[i] = i < fw ? nd.stem_b[i] : nd.conv_b[i - fw];
 }
-__device__ __forceinline__ void net_forward_wave(const NetDev &nd, _Float16 *a0, _Float16 *a1, const float4 *mlp,
-                                                 const float *bias_lds, uint64_t bA0, uint64_t bA1, uint64_t bB0, uint64_t bB1,
-                                                 int npos, float *__restrict__ values, float *__restrict__ priors, int outA,
-                                                 int outB, unsigned long long *stamps = nullptr)
-{
-    if (npos >= 2) net_forward_wave_nt<3>(nd, a0, a1, mlp, bias_lds, bA0, bA1, bB0, bB1, 2, values, priors, outA, outB, stamps);
-    else net_forward_wave_nt<2>(nd, a0, a1, mlp, bias_lds, bA0, bA1, bA0, bA1, 1, values, priors, outA, outA, stamps);
-}
-
 }  // namespace c4net
 
 // host-side handle behind c4_net_* (include/c4_engine.h)

@@ -308,8 +308,8 @@ int c4_net_destroy(c4_net *net);
  * c4_step (c4_leaf_buffers).  Asynchronous on hip_stream. */
 int c4_net_forward(c4_net *net, void *hip_stream, const uint64_t *color0_dev, const uint64_t *color1_dev,
                    int32_t n, float *values_dev, float *priors_dev);
-/* c4_net_forward evaluated by the wave-private forward the fused self-play kernel uses (one wave = two
- * positions, no workgroup barrier).  Same arguments, bit-identical answers. */
+/* c4_net_forward evaluated by the wave-private forward the fused self-play kernel uses (one wave = one
+ * position, no workgroup barrier).  Same arguments, bit-identical answers. */
 int c4_net_forward_wave(c4_net *net, void *hip_stream, const uint64_t *color0_dev, const uint64_t *color1_dev,
                         int32_t n, float *values_dev, float *priors_dev);
 const char *c4_net_last_error(void);

@@ -57,10 +57,11 @@ def test_fused_net_vs_pytorch_fp32(oracle, n):
 
 @pytest.mark.parametrize("n", [1, 2, 3, 16, 33, 4099])
 def test_wave_private_forward_is_bit_identical(oracle, n):
-    """c4_net_forward_wave (one wave = two positions, no workgroup barrier: what the wave-autonomous
-    self-play kernel evaluates its leaves with) must answer exactly what c4_net_forward answers --
-    same per-element arithmetic in the same order -- for even, odd and ragged batch sizes, and with a
-    different tower depth (the runtime-depth path)."""
+    """c4_net_forward_wave (one wave = one position on 16-row MFMA tiles, no workgroup barrier: what the
+    wave-autonomous self-play kernel evaluates its leaves with) must answer exactly what c4_net_forward
+    answers (32-row tiles, 16 positions per workgroup) -- same per-element arithmetic, and one 16x16x32 MFMA
+    step accumulates exactly like two 32x32x16 steps -- for any batch size, and with a different tower depth
+    (the runtime-depth path)."""
     from connect4_amd.fused_net import FusedNet
     from connect4_amd.net import NetConfig, random_init_state_dict
     for n_res in (3, 1):

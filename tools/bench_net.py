@@ -14,7 +14,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=200)
-    ap.add_argument("--wave", type=int, default=0, help="1: the wave-private forward (two positions per wave)")
+    ap.add_argument("--wave", type=int, default=0, help="1: the wave-private forward (one position per wave)")
     args = ap.parse_args()
     from connect4_amd.fused_net import FusedNet
     from connect4_amd.net import InferenceNet, random_init_state_dict

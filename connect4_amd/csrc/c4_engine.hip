@@ -576,7 +576,7 @@ template <> __device__ __forceinline__ void store_plane<hip_bfloat16>(void *p, s
 // DevT: `const Dev` (kernel argument, held in SGPRs) or a constant-address-space view of the engine's device
 // copy: the wave kernel reads each field with a scalar load where it is used instead of holding ~70
 // argument SGPRs (most of them spilled to VGPR lanes) for its whole lifetime.
-template <int EVAL, bool STAMPS = true, bool LDS_STATE = false, bool WAVE_SYNC = false, class DevT = const Dev>
+template <int EVAL, bool STAMPS = true, bool LDS_STATE = false, bool WAVE_SYNC = false, bool PATH_KEPT = false, class DevT = const Dev>
 __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, const int gl,
                                           PathEntry (*s_path)[MAX_DEPTH], Rec (*s_l1)[GROUP],
                                           const void *__restrict__ values_in,
@@ -626,7 +626,9 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
     uint64_t leaf0 = 0, leaf1 = 0;
     double ev_value = 0.0, ev_prior = 0.0;   // ev_prior: lane k holds prior[k]
     bool apply_now = false;
-    bool path_lds = (EVAL == C4_EVAL_CENTRE);   // where the pending leaf's descent path lives
+    // where the pending leaf's descent path lives.  PATH_KEPT: the caller keeps every slot's path stack in LDS of its
+    // own for the whole launch (no global round trip between emitting a leaf and applying its answer)
+    bool path_lds = (EVAL == C4_EVAL_CENTRE) || PATH_KEPT;
     bool fresh_eval = false;                    // the answer came from the evaluator: remember it
     if (pend >= 0) {
         leaf0 = LDS_STATE ? sm->leaf0 : d.leaf_c0[g];
@@ -660,6 +662,8 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
     // Hot subtree in LDS: once a launch has loaded the root's sibling block it stays in s_l1 for all
     // further simulations of the launch (write-through on every backup), so level 1 of every later
     // descent is an LDS read instead of an HBM round trip.
+    // (keeping the block valid from one tree call to the next, possible where the slot has LDS of its own, measured
+    // -0.2 %: the reload is an L1/L2 hit, the bookkeeping is not free)
     bool l1_valid = false;
     int inner = 0;
     const unsigned long long wave_mask0 = WAVE_SYNC ? __builtin_amdgcn_ballot_w64(true) : 0ull;
@@ -1116,7 +1120,8 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                 continue;
             }
         }
-        for (uint32_t i = lane; i < depth; i += GROUP) gpath[i] = s_path[gl][i];
+        if (!PATH_KEPT)
+            for (uint32_t i = lane; i < depth; i += GROUP) gpath[i] = s_path[gl][i];
         has_leaf = 1;
         break;
     }
@@ -1347,7 +1352,14 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
     __shared__ uint32_t s_stats[N_STATS];
     __shared__ __attribute__((aligned(16))) float s_bias[BIAS_LDS_FLOATS];   // stem + conv biases (when the tower fits)
     __shared__ __attribute__((aligned(16))) uint16_t s_tab16[(MODE == NETMODE_F32_F16) ? 64 * TAB16 : 8];   // tap offsets of net_forward_wave16
-    static_assert((sizeof(PathEntry) * MAX_DEPTH + sizeof(Rec) * GROUP) * SPW <= sizeof(_Float16) * WBUF, "a wave's path stacks must fit its activation planes");
+    // 32-filter fp16 net (small planes): per slot and for the whole launch, LDS of its own for the descent path of the
+    // simulation in flight (a leaf that waits for the network needs no copy of its path in global memory) and for the
+    // root's sibling block (hot subtree).  The wider planes of the other modes leave no room: there the path stacks
+    // alias the wave's planes (dead while the tree runs) and a waiting leaf's path goes through global memory.
+    constexpr bool OWN_PATH = MODE == NETMODE_F32_F16;
+    __shared__ __attribute__((aligned(16))) PathEntry s_path_own[OWN_PATH ? TS : 1][MAX_DEPTH];
+    __shared__ __attribute__((aligned(16))) Rec s_l1_own[OWN_PATH ? TS : 1][GROUP];
+    static_assert(OWN_PATH || (sizeof(PathEntry) * MAX_DEPTH + sizeof(Rec) * GROUP) * SPW <= sizeof(_Float16) * WBUF, "a wave's path stacks must fit its activation planes");
     const int slot0 = blockIdx.x * TS;
     const int wv = threadIdx.x >> 6;
     // ---- launch prologue: slot states, pending answers and the MLP tables, global -> LDS
@@ -1374,11 +1386,15 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
     for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
     stage_bias_lds(nd, s_bias);
     if (MODE == NETMODE_F32_F16 && threadIdx.x < 64) build_tab16(s_tab16, threadIdx.x);
+    if (OWN_PATH)
+        for (int i = threadIdx.x; i < TS * MAX_DEPTH; i += NTHREADS) {   // paths of leaves pending from the previous launch
+            const int p = i / MAX_DEPTH, k = i - p * MAX_DEPTH;
+            if (slot0 + p < d.G) s_path_own[p][k] = d.path[(size_t)(slot0 + p) * MAX_DEPTH + k];
+        }
     __syncthreads();
+    PathEntry (*s_path)[MAX_DEPTH] = OWN_PATH ? s_path_own : reinterpret_cast<PathEntry (*)[MAX_DEPTH]>(&act[wv][0]);
+    Rec (*s_l1)[GROUP] = OWN_PATH ? s_l1_own : reinterpret_cast<Rec (*)[GROUP]>(&act[wv][0] + sizeof(PathEntry) * MAX_DEPTH * SPW / sizeof(_Float16));
     // (a tree call ends when a slot of the wave blocks; max_inner bounds it)
-    // the wave's path stacks and hot sibling blocks alias its first activation buffer (dead while the tree runs)
-    PathEntry (*s_path)[MAX_DEPTH] = reinterpret_cast<PathEntry (*)[MAX_DEPTH]>(&act[wv][0]);
-    Rec (*s_l1)[GROUP] = reinterpret_cast<Rec (*)[GROUP]>(&act[wv][0] + sizeof(PathEntry) * MAX_DEPTH * SPW / sizeof(_Float16));
     unsigned long long t_tree = 0, t_net = 0, n_pass = 0;   // diagnostic (C4_TREE_STAMPS=1)
     // A launch is a time quantum, not a number of rounds: every wave keeps alternating tree work and
     // network passes until n_steps * time_budget cycles have passed, so all waves of the launch end
@@ -1393,8 +1409,8 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
         const int grp = (tid & 63) / GROUP;
         const int sl = (tid >> 6) + NWAVES * grp;     // slot of this 8-lane group inside the workgroup
         if (grp < SPW)
-            tree_step<C4_EVAL_EXTERNAL_F32, false, true, true>(d, slot0 + sl, lane, grp, s_path, s_l1, s_val, s_pri, nullptr, nullptr,
-                                                               &smem[sl], sl, s_stats, t_launch + quantum);
+            tree_step<C4_EVAL_EXTERNAL_F32, false, true, true, OWN_PATH>(d, slot0 + sl, lane, OWN_PATH ? sl : grp, s_path, s_l1, s_val, s_pri, nullptr,
+                                                                         nullptr, &smem[sl], sl, s_stats, t_launch + quantum);
         lds_fence();   // the slot states written by the groups' first lanes are read by the whole wave
         const unsigned long long tb = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
         // the wave's own leaves, two per network pass
@@ -1426,6 +1442,11 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
     }
     __syncthreads();
     // ---- launch epilogue: LDS -> global
+    if (OWN_PATH)
+        for (int i = threadIdx.x; i < TS * MAX_DEPTH; i += NTHREADS) {   // paths of the leaves still waiting for their answers
+            const int p = i / MAX_DEPTH, k = i - p * MAX_DEPTH;
+            if (slot0 + p < d.G && smem[p].has_leaf()) d.path[(size_t)(slot0 + p) * MAX_DEPTH + k] = s_path_own[p][k];
+        }
     if (threadIdx.x < TS && slot0 + threadIdx.x < d.G) {
         const int p = threadIdx.x, g = slot0 + p;
         const SlotMem m = smem[p];

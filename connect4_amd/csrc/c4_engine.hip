@@ -932,25 +932,31 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
         // Software-pipelined level loop: the sibling block (and score-table entry) of the NEXT level is requested
         // the moment the argmax is known, in front of this level's bookkeeping (board replay, path entry,
         // counters), so that bookkeeping runs under the load instead of in front of it.
-        Rec r = {};
-        double2 ab = {0.0, 0.0};
-        bool go = info_status(cinfo) == ST_EVALUATED && levels_left > 0;
+        // All 8 lanes of the group load "their" record of the 8-record sibling block, also the lanes beyond the node's
+        // children (their records exist in the pool and are never scored): no predicate, no zero fill on the loads.
+        // The level budget is a feature of c4_step; the wave-autonomous kernel (WAVE_SYNC) bounds its calls by time.
+        constexpr bool BUDGET = !WAVE_SYNC;
+        Rec r;
+        double2 ab;
+        bool go = info_status(cinfo) == ST_EVALUATED && (!BUDGET || levels_left > 0);
         if (go) {
-            const bool act0 = lane < (int)info_nchild(cinfo);
             ab = d.tabAB[cN];
             asm volatile("" ::: "memory");   // the score-table entry is requested first (its latency hides under the block's)
             if (depth == 0 && l1_valid) {
-                if (act0) r = s_l1[gl][lane];                          // hot subtree: LDS
+                r = s_l1[gl][lane];                                    // hot subtree: LDS
             } else {
-                if (act0) r = *pool.rec(info_base(cinfo) + lane);      // two 16-byte loads per lane
+                r = *pool.rec(info_base(cinfo) + lane);                // two 16-byte loads per lane
                 if (depth == 0) {                                      // first descent of the launch: stage the block
-                    if (act0) s_l1[gl][lane] = r;
+                    s_l1[gl][lane] = r;
                     l1_valid = true;
                 }
             }
+        } else {
+            r = Rec{};
+            ab = double2{0.0, 0.0};
         }
         while (go) {
-            levels_left -= 1;
+            if (BUDGET) levels_left -= 1;
             const uint32_t cb = info_base(cinfo), nc = info_nchild(cinfo), pf64 = info_pf64(cinfo);
             if (cN == 1) st.expansions += 1;   // first descent through an evaluated node == expand_node
             const bool act = lane < (int)nc;
@@ -968,13 +974,13 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             Pick best{s, act ? lane : -1, n, inf, w};
             group_pick(best);                                   // mcts.py:141-142 max((score, child))
             // ---- next level's request
-            go = info_status(best.info) == ST_EVALUATED && levels_left > 0;
-            Rec rn = {};
-            double2 abn = {0.0, 0.0};
+            go = info_status(best.info) == ST_EVALUATED && (!BUDGET || levels_left > 0);
+            Rec rn = r;
+            double2 abn = ab;
             if (go) {
                 abn = d.tabAB[best.n];
                 asm volatile("" ::: "memory");
-                if (lane < (int)info_nchild(best.info)) rn = *pool.rec(info_base(best.info) + lane);
+                rn = *pool.rec(info_base(best.info) + lane);
             }
             // ---- this level's bookkeeping
             cN = best.n;

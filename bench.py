@@ -153,7 +153,15 @@ def launch_ranks(args, argv):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
-    proc = subprocess.Popen(cmd, env=env, cwd=ROOT)
+    # rank 0's JSON line is the only thing this process prints on stdout; whatever else the ranks or their
+    # libraries write there (e.g. gloo's connection notes) is passed on to stderr
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
     return proc.wait()
 
 

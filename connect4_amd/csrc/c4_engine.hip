@@ -1431,7 +1431,8 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
         if (MODE == NETMODE_F32_F16) {   // 32 filters, fp16: one position per pass on 16-row MFMA tiles
             for (int i = 0; i < cnt; ++i) {
                 const int sa = pend_slot[i];
-                net_forward_wave16(nd, &act[wv][0], mlp, s_bias, s_tab16, smem[sa].leaf0, smem[sa].leaf1, s_val, s_pri, sa);
+                net_forward_wave16(nd, &act[wv][0], mlp, s_bias, s_tab16, smem[sa].leaf0, smem[sa].leaf1, s_val, s_pri, sa,
+                                   (C4_FUSED_NET_STAMPS && d.has_stamps && blockIdx.x < 16) ? d.cold->stamps + 2048 + (blockIdx.x * NWAVES + wv) * 16 : nullptr);
             }
         } else {   // reference-precision net or 64 filters: one position per pass on 32-row tiles
             for (int i = 0; i < cnt; ++i) {

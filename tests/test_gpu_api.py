@@ -221,8 +221,18 @@ def test_mini_generation_selfplay_train_reload(tmp_path):
     assert d["boards"].shape == (2 * n_pos, 3, 6, 7) and d["values"].shape == (2 * n_pos,) and d["priors"].shape == (2 * n_pos, 7)
     assert os.path.exists(os.path.join(str(tmp_path), "0", "net.pth"))
     assert not torch.equal(w0, tr.net.state_dict()["body.0.0.weight"].cpu())
-    games1, _ = run_generation(tr, MCTSConfig.self_play(24), n_games=48, save_dir=str(tmp_path), gen=1, n_slots=48)
-    assert len(games1) == 48
+    t1 = {}
+    games1, _ = run_generation(tr, MCTSConfig.self_play(24), n_games=48, save_dir=str(tmp_path), gen=1, n_slots=48, timings=t1)
+    assert len(games1) == 48 and t1["training_rows"] == 2 * games1.n_positions      # window of generation 1: itself
+    # the sliding window (data.py:66-75): generation 3 trains on generations 3 and 2, newest first
+    games2, _ = run_generation(tr, MCTSConfig.self_play(24), n_games=48, save_dir=str(tmp_path), gen=2, n_slots=48)
+    t3 = {}
+    games3, _ = run_generation(tr, MCTSConfig.self_play(24), n_games=48, save_dir=str(tmp_path), gen=3, n_slots=48,
+                               write_games_pkl=True, timings=t3)
+    assert t3["training_rows"] == 2 * (games3.n_positions + games2.n_positions)
+    from connect4_amd.data import load_games
+    back = load_games(os.path.join(str(tmp_path), "3"))
+    assert [g.moves for g in back] == [g.moves for g in games3.to_game_data()]
 
 
 def test_end_to_end_net_driven_search_matches_reference():

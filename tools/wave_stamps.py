@@ -41,11 +41,16 @@ sp.synchronize(); t0 = time.perf_counter(); sp.run_steps(6400); sp.synchronize()
 s2 = sp.stats()
 print("wall: %.1f us/step, %.1f M sims/s" % (dt / 6400 * 1e6, (s2["simulations"] - s1["simulations"]) / dt / 1e6))
 print("simulations per slot and step: %.2f" % ((s1["simulations"] - s0["simulations"]) / 64.0 / slots))
-# phases of the last network pass of each wave of workgroups 0..15, measured inside the fused kernel
+# phases of the last network pass of each wave of workgroups 0..15, measured inside the fused kernel: needs a
+# diagnostic build of the library (hipcc ... -DC4_FUSED_NET_STAMPS=1 -o x.so; C4_ENGINE_LIB=x.so): the production
+# kernel carries no stamp pointer (it cost 3 %)
 out2 = (C.c_uint64 * 2048)()
 assert sp.engine._lib.c4_debug_fused_net_stamps(sp.engine._h, out2) == 0
 st = np.array(list(out2), dtype=np.int64).reshape(128, 16)
 st = st[st[:, 0] > 0]
+if len(st) == 0:
+    print("(no in-fused network stamps: production build)")
+    sys.exit(0)
 names = ["stem"] + ["L%d" % i for i in range(6)] + ["tower_end", "heads", "mlp"]
 d = st[:, 1:11] - st[:, 0:10]
 print("in-fused network pass (%d waves sampled), cycles per phase (median): " % len(st) +

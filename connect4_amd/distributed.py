@@ -51,7 +51,10 @@ def generate_games_sharded_packed(config, net, n_games: int, seed: int = 0, devi
     start, count = shard_range(n_games, rank, world)
     packed = generate_games_packed(config, net, count, seed=rank_seed(seed, rank), device=device, **kw).offset_ids(start)
     if world > 1 and gather:
-        packed = all_gather_packed(packed)
+        if dist.get_backend() == "nccl":
+            packed = all_gather_packed(packed)                      # device tensors over RCCL / xGMI
+        else:                                                       # gloo (rehearsals, tests): through host memory
+            packed = all_gather_packed(packed.cpu()).to(packed.device)
     return packed.sorted_by_id()
 
 

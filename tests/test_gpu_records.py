@@ -146,3 +146,54 @@ def test_eval_cache_lookup_returns_the_nets_answers():
     assert not f2[0]
     sp.close()
     net.close()
+
+
+def _sharded_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from connect4_amd.config import MCTSConfig
+    from connect4_amd.distributed import generate_games_sharded_packed
+    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.net import random_init_state_dict
+    net = FusedNet(random_init_state_dict(seed=0))
+    p = generate_games_sharded_packed(MCTSConfig.self_play(16), net, 21, seed=5, device=0, n_slots=16)
+    q.put((rank, p.ids.tolist(), p.lengths.tolist(), p.moves.cpu().tolist(), str(p.device)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_generation_two_ranks_one_card():
+    """BASELINE configs[2] shape in miniature: two ranks (both on this card, gloo) play disjoint shards with RNG
+    streams seed+rank, export on the device and all-gather the packed tensors: every rank ends with all 21 games,
+    sorted by global id, identical on both ranks; the shards are the ones a single rank plays with those seeds."""
+    import socket
+    import torch.multiprocessing as mp
+    from connect4_amd.config import MCTSConfig
+    from connect4_amd.distributed import rank_seed, shard_range
+    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.net import random_init_state_dict
+    from connect4_amd.selfplay import generate_games_packed
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert outs[0][1:4] == outs[1][1:4] and outs[0][1] == list(range(21)) and outs[0][4].startswith("cuda")
+    net = FusedNet(random_init_state_dict(seed=0))
+    want_moves = []
+    for r in range(2):
+        start, count = shard_range(21, r, 2)
+        part = generate_games_packed(MCTSConfig.self_play(16), net, count, seed=rank_seed(5, r), n_slots=16)
+        want_moves += part.moves.cpu().tolist()
+    assert outs[0][3] == want_moves

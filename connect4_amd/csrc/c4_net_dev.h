@@ -50,7 +50,15 @@ struct NetDev {
     unsigned long long *stamps;   // diagnostic only (C4_NET_STAMPS=1): [wave][16] s_memtime values of block 0
 };
 
-__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, LEAK * v); }   // slope < 1
+// LeakyReLU = max(v, 0.01 v) (slope < 1).  Written as the bare instruction: fmaxf() makes the compiler canonicalise
+// the MFMA's output first (a second v_max_f32 per value, a tenth of the wave forward's vector instructions); the
+// result is the same for every non-NaN input, and a NaN never gets here (the engine counts and replaces bad answers).
+__device__ __forceinline__ float lrelu(float v)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(LEAK * v));
+    return r;
+}
 
 // DPP cross-lane moves (VALU speed; ds_bpermute-based __shfl costs an LDS round trip each)
 template <int CTRL>

@@ -394,6 +394,7 @@ def run_rank(args):
             pmc_ok = (pmc.get("kernel", "") == "c4_selfplay_wave_kernel" and args.slots == pmc.get("slots") and args.sims == pmc.get("sims")
                       and args.max_inner == pmc.get("max_inner") and args.quanta_per_step == pmc.get("quanta_per_launch")
                       and args.time_budget == pmc.get("time_budget_cycles") and args.net_precision == pmc.get("net_precision", "f16")
+                      and args.filters == pmc.get("filters", 32) and args.residuals == pmc.get("residuals", 3)
                       and "FETCH_SIZE_fused" in pmc)
             fused = {
                 "kernel": "c4_selfplay_wave_kernel (per wave: PUCT tree walk of its slots + policy/value net on their leaves; the only kernel of the timed region)",

@@ -86,3 +86,94 @@ def test_config4_8192_searches_3200_sims_vs_oracle(oracle):
         assert roots[i].move == mv and roots[i].expansions == info.n_expansions
         exp += info.n_expansions
     assert exp > 0
+
+
+def _popcount_cols(occ):
+    """[n] int64 occupancy -> [n, 7] stones per column (torch, any device)."""
+    import torch
+    cols = []
+    for c in range(7):
+        col = (occ >> (7 * c)) & 0x3f
+        cnt = torch.zeros_like(col)
+        for r in range(6):
+            cnt = cnt + ((col >> r) & 1)
+        cols.append(cnt)
+    return torch.stack(cols, 1)
+
+
+def _wins(b):
+    """board.py:173-184 on a tensor of int64 bitboards."""
+    out = None
+    for s in (6, 7, 8, 1):
+        y = b & (b >> s)
+        hit = (y & (y >> (2 * s))) != 0
+        out = hit if out is None else (out | hit)
+    return out
+
+
+def test_soak_production_selfplay_every_record_is_a_legal_complete_game():
+    """Ten seconds of the production configuration -- 4096 games x 800 simulations, Philox RNG, evaluation cache,
+    device-side export behind every launch -- and EVERY exported game (~150 k games, ~4.5 M positions) is checked on
+    the device with vectorised bit arithmetic: plies chain (board + recorded move = next board, o and x alternate, the
+    move is legal), the first board is empty, the last move ends the game with the recorded result (four in a row for
+    the mover, or a full board without one) and no earlier position was already decided, policies are distributions
+    over legal columns, values lie in [0, 1], ids are unique and nothing was dropped.  (The exact, move-for-move
+    parity of this path is test_config1_...; this one is about the record machinery at scale: ring, staging, export.)"""
+    import time
+    import torch
+    from connect4_amd.config import MCTSConfig
+    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.net import random_init_state_dict
+    from connect4_amd.packed import PackedGames
+    from connect4_amd.selfplay import SelfPlay
+    G = 4096
+    net = FusedNet(random_init_state_dict(seed=0))
+    sp = SelfPlay(net, G, MCTSConfig.self_play(800), seed=7, games_target=-1, record_capacity_games=2 * G, use_graph=False,
+                  fused_loop=True, steps_per_launch=256, max_inner_iters=32)
+    parts = []
+    t0 = time.time()
+    while time.time() - t0 < 10.0:
+        for _ in range(8):
+            sp.run_steps(256)
+        parts.append(sp.engine.export_games())          # consumes what finished; synchronises
+    st = sp.stats()
+    parts.append(sp.engine.export_games())
+    sp.close()
+    net.close()
+    p = PackedGames.cat(parts)
+    assert st["dropped_games"] == 0 and st["bad_evals"] == 0
+    assert p.n_games == st["games_finished"] and p.n_games > 50_000
+    assert torch.unique(p.ids).numel() == p.n_games
+    L = p.lengths.long()
+    assert int(L.min()) >= 7 and int(L.max()) <= 42 and int(L.sum()) == p.n_positions
+    first = torch.cumsum(L, 0) - L                          # index of every game's first position
+    last = first + L - 1
+    c0, c1 = p.boards[:, 0], p.boards[:, 1]
+    occ = c0 | c1
+    mv = p.moves.long()
+    ply = torch.arange(p.n_positions, device=occ.device) - first[p.game_index.long()]
+    heights = _popcount_cols(occ)
+    assert torch.equal(heights.sum(1), ply)                 # ply = stones on the board; o moves on even plies
+    assert bool(((c0 & c1) == 0).all()) and bool((c0[first] == 0).all()) and bool((c1[first] == 0).all())
+    h = heights.gather(1, mv[:, None])[:, 0]
+    assert bool((h < 6).all())                              # the recorded move is legal
+    stone = torch.ones_like(occ) << (7 * mv + h)
+    n0 = torch.where(ply % 2 == 0, c0 | stone, c0)
+    n1 = torch.where(ply % 2 == 1, c1 | stone, c1)
+    inner = torch.ones(p.n_positions, dtype=torch.bool, device=occ.device)
+    inner[last] = False
+    nxt = torch.nonzero(inner)[:, 0]
+    assert torch.equal(n0[nxt], c0[nxt + 1]) and torch.equal(n1[nxt], c1[nxt + 1])     # plies chain inside a game
+    assert not bool((_wins(c0) | _wins(c1)).any())          # no recorded position was already decided
+    owin, xwin = _wins(n0[last]), _wins(n1[last])
+    full = (ply[last] + 1) == 42
+    res = p.results.long()
+    assert torch.equal(res, torch.where(owin, 2, torch.where(xwin, 0, 1)))
+    assert bool((owin | xwin | full).all()) and bool((~(owin & xwin)).all())
+    assert torch.equal(p.targets, 0.5 * res[p.game_index.long()].float())
+    pol = p.policy
+    assert bool((pol >= 0).all()) and bool(((pol.sum(1) - 1).abs() < 1e-5).all())
+    assert bool((pol[heights >= 6] == 0).all())             # no mass on full columns
+    v = p.values[~torch.isnan(p.values)]
+    assert bool(((v >= 0) & (v <= 1)).all())
+    print("soak: %d games, %d positions checked on the device in %.1f s of self-play" % (p.n_games, p.n_positions, time.time() - t0))

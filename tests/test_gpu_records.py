@@ -197,3 +197,46 @@ def test_sharded_generation_two_ranks_one_card():
         part = generate_games_packed(MCTSConfig.self_play(16), net, count, seed=rank_seed(5, r), n_slots=16)
         want_moves += part.moves.cpu().tolist()
     assert outs[0][3] == want_moves
+
+
+def _rccl_worker(port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from connect4_amd.config import MCTSConfig
+    from connect4_amd.distributed import generate_games_sharded_packed
+    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.net import random_init_state_dict
+    from connect4_amd.packed import all_gather_packed
+    net = FusedNet(random_init_state_dict(seed=0))
+    p = generate_games_sharded_packed(MCTSConfig.self_play(16), net, 12, seed=5, device=0, n_slots=12, gather=False)
+    g = all_gather_packed(p)                      # RCCL all_gather of every field's dtype (int64, uint8, int8, int32, float32)
+    ok = all(torch.equal(getattr(p, k), getattr(g, k)) for k in ("boards", "moves", "values", "policy", "targets", "lengths", "results", "ids"))
+    t = torch.ones(3, device="cuda")
+    dist.all_reduce(t)
+    dist.barrier()
+    q.put((ok, g.n_games, str(g.device), dist.get_backend(), float(t.sum())))
+    dist.destroy_process_group()
+
+
+def test_packed_all_gather_runs_on_rccl():
+    """The generation-end collective on the real backend (RCCL; one rank is all this box has): every dtype of the packed
+    record goes through dist.all_gather on device tensors and comes back unchanged."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    ok, n, dev, backend, red = q.get(timeout=300)
+    p.join(120)
+    assert p.exitcode == 0
+    assert ok and n == 12 and dev.startswith("cuda") and backend == "nccl" and red == 3.0

@@ -1959,10 +1959,11 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
         if (bits == 0 && cfg->eval_mode == C4_EVAL_EXTERNAL_F32 && !cfg->stop_after_move) {
             // The reference's table lives as long as its player and is shared by all its games
             // (evaluators.py:9-25), so positions of earlier games keep answering: size it for many
-            // games' worth of evaluations -- 64 x slots x simulations entries (12.9 GB for the 4096-game
-            // configuration: hit rate 70 % -> 81 %, +19 % throughput over a 4x table), at most 2^29
-            // entries and a quarter of the free device memory (288 GB of HBM is there to be used).
-            const uint64_t want = 64ULL * (uint64_t)cfg->n_slots * ((uint64_t)cfg->simulations + 1);
+            // games' worth of evaluations -- 128 x slots x simulations entries (2^29 = 25.8 GB for the 4096-game
+            // configuration; measured there: 2^25 227 M, 2^26 238, 2^27 245, 2^28 249, 2^29 252, 2^30 254 M
+            // expansions/s as the hit rate climbs from 74 % to 81 % and direct-mapped collisions thin out), at most
+            // 2^29 entries and a quarter of the free device memory (288 GB of HBM is there to be used).
+            const uint64_t want = 128ULL * (uint64_t)cfg->n_slots * ((uint64_t)cfg->simulations + 1);
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
             bits = 16;

@@ -1348,8 +1348,9 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
     const_dev &d = *(const_dev *)d_dev;   // engine description: scalar loads from constant memory at the point of use
     constexpr int SPW = TS / NWAVES;   // slots per wave
     static_assert(TS % NWAVES == 0 && SPW >= 1 && SPW <= 8, "slots per workgroup");
-    // private activation planes of the waves: the one-position forward on 16-row tiles needs 2 x 4,128 B, the others 2 x 7,760 B
-    constexpr int WBUF = (MODE == NETMODE_F32_F16) ? 2 * PLANE16 : 2 * WACT;
+    // private activation planes of the waves: the one-position forward on 16-row tiles needs 2 x 4,128 B (4 x with the
+    // low-part planes of the reference-precision mode), the 64-filter forward 2 x 7,760 B
+    constexpr int WBUF = WaveBuf<MODE>::HALVES;
     __shared__ __attribute__((aligned(16))) _Float16 act[NWAVES][WBUF];
     __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
     __shared__ SlotMem smem[TS];
@@ -1357,7 +1358,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
     __shared__ float s_pri[TS * 7];
     __shared__ uint32_t s_stats[N_STATS];
     __shared__ __attribute__((aligned(16))) float s_bias[BIAS_LDS_FLOATS];   // stem + conv biases (when the tower fits)
-    __shared__ __attribute__((aligned(16))) uint16_t s_tab16[(MODE == NETMODE_F32_F16) ? 64 * TAB16 : 8];   // tap offsets of net_forward_wave16
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab16[(MODE != NETMODE_F64) ? 64 * TAB16 : 8];   // tap offsets of net_forward_wave16
     // 32-filter fp16 net (small planes): per slot and for the whole launch, LDS of its own for the descent path of the
     // simulation in flight (a leaf that waits for the network needs no copy of its path in global memory) and for the
     // root's sibling block (hot subtree).  The wider planes of the other modes leave no room: there the path stacks
@@ -1391,7 +1392,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
     }
     for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
     stage_bias_lds(nd, s_bias);
-    if (MODE == NETMODE_F32_F16 && threadIdx.x < 64) build_tab16(s_tab16, threadIdx.x);
+    if (MODE != NETMODE_F64 && threadIdx.x < 64) build_tab16(s_tab16, threadIdx.x);
     if (OWN_PATH)
         for (int i = threadIdx.x; i < TS * MAX_DEPTH; i += NTHREADS) {   // paths of leaves pending from the previous launch
             const int p = i / MAX_DEPTH, k = i - p * MAX_DEPTH;
@@ -1437,7 +1438,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
         } else {   // reference-precision net or 64 filters: one position per pass on 32-row tiles
             for (int i = 0; i < cnt; ++i) {
                 const int sa = pend_slot[i];
-                net_forward_wave1_mode<MODE>(nd, &act[wv][0], mlp, s_bias, smem[sa].leaf0, smem[sa].leaf1, s_val, s_pri, sa);
+                net_forward_wave1_mode<MODE>(nd, &act[wv][0], mlp, s_bias, s_tab16, smem[sa].leaf0, smem[sa].leaf1, s_val, s_pri, sa);
             }
         }
         lds_fence();   // answers (LDS) before the next tree_step reads them

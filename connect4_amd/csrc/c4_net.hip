@@ -53,24 +53,26 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_kernel(NetDev nd, const uint6
     net_forward_block(nd, NetLds{lds, wbuf, mlp}, c0, c1, n, blockIdx.x * P, values, priors);
 }
 
-// One-position wave-private forward (net_forward_wave1: reference precision at 32 filters, fp16 at 64 filters): one
-// position per wave.  Both c4_net_forward and c4_net_forward_wave run this kernel for such a net (one
+// One-position wave-private forward (net_forward_wave16p: reference precision at 32 filters; net_forward_wave1: fp16 at
+// 64 filters): one position per wave.  Both c4_net_forward and c4_net_forward_wave run this kernel for such a net (one
 // implementation, so the two entry points and the fused self-play kernel cannot disagree).
 template <int MODE>
 __global__ __launch_bounds__(NTHREADS) void c4_net_wave1_kernel(NetDev nd, const uint64_t *__restrict__ c0,
                                                                 const uint64_t *__restrict__ c1, int n,
                                                                 float *__restrict__ values, float *__restrict__ priors)
 {
-    __shared__ __attribute__((aligned(16))) _Float16 act[NWAVES][2][WACT];
+    __shared__ __attribute__((aligned(16))) _Float16 act[NWAVES][WaveBuf<MODE>::HALVES];
     __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
     __shared__ __attribute__((aligned(16))) float s_bias[BIAS_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab[64 * TAB16];
     for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
     stage_bias_lds(nd, s_bias);
+    if (threadIdx.x < 64) build_tab16(s_tab, threadIdx.x);
     __syncthreads();
     const int wv = threadIdx.x >> 6;
     const int p = blockIdx.x * NWAVES + wv;
     if (p >= n) return;
-    net_forward_wave1_mode<MODE>(nd, &act[wv][0][0], mlp, s_bias, c0[p], c1[p], values, priors, p,
+    net_forward_wave1_mode<MODE>(nd, &act[wv][0], mlp, s_bias, s_tab, c0[p], c1[p], values, priors, p,
                                  (nd.stamps && blockIdx.x == 0) ? nd.stamps + wv * 16 : nullptr);
 }
 
@@ -141,7 +143,7 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
         snprintf(n_err, 512, "c4_net_create: unknown precision %d", desc->precision);
         return C4_EINVAL;
     }
-    if (!wave1_supported(FW, desc->precision == C4_NET_F32X3)) {
+    if (FW != 32 && desc->precision == C4_NET_F32X3) {
         snprintf(n_err, 512, "c4_net_create: the reference-precision forward is offered for 32 filters only "
                  "(the hi/lo planes of %d filters do not fit a wave's private LDS)", FW);
         return C4_EINVAL;
@@ -160,8 +162,7 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
     // holds cout 32 cb + (l & 31) and the 8 k's 16 s + 8 (l >> 5) + j.
     // ---- stem: k = tap*4 + ch (ch 3 zero), 48 = 3 k-steps
     std::vector<_Float16> stem((size_t)3 * CB * 64 * 8), conv((size_t)2 * R * KS * CB * 64 * 8), head((size_t)KPT * 64 * 8);
-    // reference-precision mode: w ~= hi + lo / 2^11 with hi = f16(w), lo = f16((w - hi) * 2^11), same fragment order
-    std::vector<_Float16> stem_l(stem.size()), conv_l(conv.size()), head_l(head.size());
+    // reference-precision mode: w ~= hi + lo / 2^11 with hi = f16(w), lo = f16((w - hi) * 2^11)
     auto split = [](float v, _Float16 &hi, _Float16 &lo) {
         hi = (_Float16)v;
         lo = (_Float16)((v - (float)hi) * LO_SCALE);
@@ -174,7 +175,7 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
                     float v = 0.0f;
                     if (tap < 9 && ch < 3) v = desc->stem_w[((co * 3 + ch) * 3 + tap / 3) * 3 + tap % 3];
                     const size_t at = (((size_t)s * CB + cb) * 64 + l) * 8 + j;
-                    split(v, stem[at], stem_l[at]);
+                    stem[at] = (_Float16)v;
                 }
     // ---- 3x3 convs: k-step s: tap = s / KPT, cin = (s % KPT)*16 + 8(l>>5) + j
     for (int L = 0; L < 2 * R; ++L)
@@ -185,29 +186,30 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
                         const int tap = s / KPT, ci = (s % KPT) * 16 + 8 * (l >> 5) + j, co = 32 * cb + (l & 31);
                         const float v = desc->conv_w[((((size_t)L * FW + co) * FW + ci) * 3 + tap / 3) * 3 + tap % 3];
                         const size_t at = ((((size_t)L * KS + s) * CB + cb) * 64 + l) * 8 + j;
-                        split(v, conv[at], conv_l[at]);
+                        conv[at] = (_Float16)v;
                     }
     // ---- head 1x1: couts 0..2 (value, policy0, policy1), cin = 16s + 8(l>>5) + j
     for (int s = 0; s < KPT; ++s)
         for (int l = 0; l < 64; ++l)
             for (int j = 0; j < 8; ++j) {
                 const int ci = 16 * s + 8 * (l >> 5) + j, co = l & 31;
-                split(co < 3 ? desc->head_w[co * FW + ci] : 0.0f, head[((size_t)s * 64 + l) * 8 + j], head_l[((size_t)s * 64 + l) * 8 + j]);
+                head[((size_t)s * 64 + l) * 8 + j] = (_Float16)(co < 3 ? desc->head_w[co * FW + ci] : 0.0f);
             }
     // ---- the same weights in v_mfma_f32_16x16x32_f16 fragment order (net_forward_wave16, 32 filters):
     //      lane l holds cout 16 ct + (l & 15) and the 8 k's 8 (l >> 4) + j of the k-step
-    std::vector<_Float16> stem16, conv16, head16;
+    std::vector<_Float16> stem16, conv16, head16, stem16l, conv16l, head16l;   // ...l: the scaled low parts
     if (FW == 32) {
         stem16.assign((size_t)4 * 64 * 8, (_Float16)0.0f);          // [k-step s][ct]: k = 32 s + 8 g + j = tap*4 + ch
         conv16.assign((size_t)std::max(1, 2 * R) * 18 * 64 * 8, (_Float16)0.0f);   // [L][tap][ct]: cin = 8 g + j
         head16.assign((size_t)64 * 8, (_Float16)0.0f);              // couts 0..2, cin = 8 g + j
+        stem16l = stem16; conv16l = conv16; head16l = head16;
         for (int s2 = 0; s2 < 2; ++s2)
             for (int ct = 0; ct < 2; ++ct)
                 for (int l = 0; l < 64; ++l)
                     for (int j = 0; j < 8; ++j) {
                         const int k = 32 * s2 + 8 * (l >> 4) + j, tap = k >> 2, ch = k & 3, co = 16 * ct + (l & 15);
-                        if (tap < 9 && ch < 3)
-                            stem16[(((size_t)s2 * 2 + ct) * 64 + l) * 8 + j] = (_Float16)desc->stem_w[((co * 3 + ch) * 3 + tap / 3) * 3 + tap % 3];
+                        const size_t at = (((size_t)s2 * 2 + ct) * 64 + l) * 8 + j;
+                        if (tap < 9 && ch < 3) split(desc->stem_w[((co * 3 + ch) * 3 + tap / 3) * 3 + tap % 3], stem16[at], stem16l[at]);
                     }
         for (int L = 0; L < 2 * R; ++L)
             for (int tap = 0; tap < 9; ++tap)
@@ -215,16 +217,17 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
                     for (int l = 0; l < 64; ++l)
                         for (int j = 0; j < 8; ++j) {
                             const int ci = 8 * (l >> 4) + j, co = 16 * ct + (l & 15);
-                            conv16[((((size_t)L * 9 + tap) * 2 + ct) * 64 + l) * 8 + j] =
-                                (_Float16)desc->conv_w[((((size_t)L * FW + co) * FW + ci) * 3 + tap / 3) * 3 + tap % 3];
+                            const size_t at = ((((size_t)L * 9 + tap) * 2 + ct) * 64 + l) * 8 + j;
+                            split(desc->conv_w[((((size_t)L * FW + co) * FW + ci) * 3 + tap / 3) * 3 + tap % 3], conv16[at], conv16l[at]);
                         }
         for (int l = 0; l < 64; ++l)
             for (int j = 0; j < 8; ++j) {
                 const int ci = 8 * (l >> 4) + j, co = l & 15;
-                if (co < 3) head16[((size_t)l) * 8 + j] = (_Float16)desc->head_w[co * FW + ci];
+                if (co < 3) split(desc->head_w[co * FW + ci], head16[((size_t)l) * 8 + j], head16l[((size_t)l) * 8 + j]);
             }
     } else {
         stem16.assign(8, (_Float16)0.0f); conv16.assign(8, (_Float16)0.0f); head16.assign(8, (_Float16)0.0f);
+        stem16l = stem16; conv16l = conv16; head16l = head16;
     }
     std::vector<float> stem_b(desc->stem_b, desc->stem_b + FW), conv_b(desc->conv_b, desc->conv_b + (size_t)2 * R * FW),
         head_b(4, 0.0f), mlp((size_t)MLP_F4 * 4, 0.0f);
@@ -248,15 +251,15 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
             if (seg == 0) pb[l] = desc->pfc_b[o];
         }
     }
-    if (conv.empty()) { conv.resize(8); conv_l.resize(8); }
+    if (conv.empty()) conv.resize(8);
     if (conv_b.empty()) conv_b.resize(4);
     hipError_t r = hipSuccess;
     const _Float16 *p16;
 #define UP16(vec, field) if (r == hipSuccess) { r = upload(net, vec, &p16); net->d.field = (const half8 *)p16; }
 #define UP32(vec, field) if (r == hipSuccess) r = upload(net, vec, &net->d.field);
     UP16(stem, stem_w) UP16(conv, conv_w) UP16(head, head_w)
-    UP16(stem_l, stem_wl) UP16(conv_l, conv_wl) UP16(head_l, head_wl)
     UP16(stem16, stem_w16) UP16(conv16, conv_w16) UP16(head16, head_w16)
+    UP16(stem16l, stem_w16l) UP16(conv16l, conv_w16l) UP16(head16l, head_w16l)
     UP32(stem_b, stem_b) UP32(conv_b, conv_b) UP32(head_b, head_b)
     {
         const float *pm = nullptr;

@@ -40,13 +40,13 @@ struct NetDev {
     const float4 *mlp;     // MLP_F4 float4s: value table [11][64][4], policy table [11][64], fc_b[64], vout_w[64], pfc_b[64]
     float vout_b, w1, w2;
     int n_res;
-    // reference-precision mode (C4_NET_F32X3): the scaled low parts of the same weights, same fragment order
-    const half8 *stem_wl, *conv_wl, *head_wl;
-    int precise;
+    int precise;           // reference-precision mode (C4_NET_F32X3)
     int filters;           // 32 or 64
     int mode;              // NETMODE_* the kernels are specialised for
-    // 32 filters, fp16: the same weights in the fragment order of v_mfma_f32_16x16x32_f16 (net_forward_wave16)
+    // 32 filters: the same weights in the fragment order of v_mfma_f32_16x16x32_f16 (net_forward_wave16) ...
     const half8 *stem_w16, *conv_w16, *head_w16;
+    // ... and, for the reference-precision mode, their scaled low parts (net_forward_wave16p)
+    const half8 *stem_w16l, *conv_w16l, *head_w16l;
     unsigned long long *stamps;   // diagnostic only (C4_NET_STAMPS=1): [wave][16] s_memtime values of block 0
 };
 
@@ -437,12 +437,18 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
 constexpr int WACT = (96 + 1) * CS;          // halves of one of a wave's two private buffers as the general forward sizes them (7,760 B)
 
 // ------------------------------------------------------------------------------------------------
-// One-position wave-private forward, net_forward_wave1<FW, PRECISE>: the general form of the wave-private
-// forward -- any supported width FW (32 or 64 filters = 1 or 2 cout blocks of 32 per MFMA), optionally in
-// reference precision -- for ONE position per pass.  (net_forward_wave16 below is the tuned special case
-// FW = 32, fp16 storage, on 16-row tiles.)
+// One-position wave-private forward on 32-row tiles, net_forward_wave1<FW>: the general form of the wave-private
+// forward -- any supported width FW (32 or 64 filters = 1 or 2 cout blocks of 32 per MFMA), fp16 storage -- for ONE
+// position per pass.  It serves the 64-filter net; the 32-filter nets run the tuned 16-row-tile forwards below
+// (net_forward_wave16, and net_forward_wave16p for the reference-precision mode).
+//   * rows: the position's 42 pixels in two 32-row MFMA tiles; rows 42..63 read the zero row and are never
+//     stored, so a plane needs 43 rows of FW + 8 halves: ping/pong planes of 64 filters are 2 x 6,192 B;
+//   * weights: fragments stream from L2 through a rolling window of WDEPTH k-steps (the tower's k-steps are
+//     one linear sequence in memory, so the window rolls across layer boundaries);
+//   * heads and MLPs as in net_forward_block (fp32 VALU).
 //
-// PRECISE (C4_NET_F32X3): every fp32 operand x (folded weight, activation) is carried as two fp16 numbers
+// Reference precision (C4_NET_F32X3, net_forward_wave16p): every fp32 operand x (folded weight, activation) is
+// carried as two fp16 numbers
 //     x  ~=  hi + lo / 2^11,      hi = f16(x),   lo = f16((x - hi) * 2^11)
 // (x - hi is exact in fp32; scaling keeps lo a NORMAL fp16 of x's own magnitude), and a product of two
 // operands as three fp16 MFMAs with fp32 accumulation -- hi*hi into one accumulator, hi*lo + lo*hi into
@@ -450,13 +456,6 @@ constexpr int WACT = (96 + 1) * CS;          // halves of one of a wave's two pr
 // dropped.  Operand error 2^-22, products exact, sums in fp32: the class of an fp32 convolution whose
 // summation order differs (what the PyTorch-ROCm / MIOpen plan is against the reference's CPU convs).
 // The input planes are 0/1 (exact in fp16), so the stem needs two MFMAs per k-step, every other layer three.
-//   * rows: the position's 42 pixels in two 32-row MFMA tiles; rows 42..63 read the zero row and are never
-//     stored, so a plane needs 43 rows of FW + 8 halves: ping/pong (x hi/lo) planes fit the two private
-//     buffers of the two-position forward (2 x 7,760 B) for <32, precise> (4 x 3,440 B) and <64, fp16>
-//     (2 x 6,192 B); <64, precise> does not fit and is not offered;
-//   * weights: fragments stream from L2 through a rolling window of WDEPTH k-steps (the tower's k-steps are
-//     one linear sequence in memory, so the window rolls across layer boundaries);
-//   * heads and MLPs as in net_forward_block (fp32 VALU), fed with the folded fp32 activations.
 // ------------------------------------------------------------------------------------------------
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
 constexpr int PROWS = PIX + 1;               // 42 real rows + the zero row
@@ -470,37 +469,27 @@ template <int FW> struct Wave1Geom {
     static_assert(FW == 32 || FW == 64, "supported widths");
     static_assert(KS % WDEPTH == 0, "rolling weight window");
 };
-constexpr bool wave1_supported(int fw, bool precise) { return (fw == 32) || (fw == 64 && !precise); }
 
-template <int FW, bool PRECISE>
-__device__ __forceinline__ void wave1_store(const floatx16 &hi, const floatx16 &lo, _Float16 *dh, _Float16 *dl, int off, bool real)
+template <int FW>
+__device__ __forceinline__ void wave1_store(const floatx16 &hi, _Float16 *dh, int off, bool real)
 {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        half4 oh, ol;
+        half4 oh;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float y = PRECISE ? lrelu(hi[4 * q + i] + lo[4 * q + i] * LO_INV) : lrelu(hi[4 * q + i]);
-            const _Float16 yh = (_Float16)y;
-            oh[i] = yh;
-            if (PRECISE) ol[i] = (_Float16)((y - (float)yh) * LO_SCALE);
-        }
-        if (real) {
-            *reinterpret_cast<half4 *>(dh + off + 8 * q) = oh;
-            if (PRECISE) *reinterpret_cast<half4 *>(dl + off + 8 * q) = ol;
-        }
+        for (int i = 0; i < 4; ++i) oh[i] = (_Float16)lrelu(hi[4 * q + i]);
+        if (real) *reinterpret_cast<half4 *>(dh + off + 8 * q) = oh;
     }
 }
 
-template <int FW, bool PRECISE>
+template <int FW>
 __device__ __forceinline__ void net_forward_wave1(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds,
                                                   uint64_t b0, uint64_t b1, float *__restrict__ values,
                                                   float *__restrict__ priors, int out, unsigned long long *stamps = nullptr)
 {
     using G = Wave1Geom<FW>;
     constexpr int CB = G::CB, KPT = G::KPT, KS = G::KS, CSF = G::CSF, PLANE = G::PLANE;
-    static_assert(wave1_supported(FW, PRECISE), "this width / precision does not fit the wave's private LDS");
-    static_assert((PRECISE ? 4 : 2) * PLANE <= 2 * WACT, "planes must fit the wave's two private buffers");
+    static_assert(2 * PLANE <= 2 * WACT, "planes must fit the wave's two private buffers");
     int lane_ = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_));     // inside a persistent kernel the compiler would otherwise hoist every lane-derived address of this function out of the caller's step loop, keep them live across the tree walk and reload them from scratch mid-pass
     const int lane = lane_;
@@ -508,9 +497,8 @@ __device__ __forceinline__ void net_forward_wave1(const NetDev &nd, _Float16 *bu
     auto stamp = [&](int i) { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); };
     stamp(0);
     const int n_layers = 2 * nd.n_res;
-    // planes: ping (p0) and pong (p1), each hi (and lo when PRECISE)
-    _Float16 *const p0h = buf, *const p0l = buf + PLANE;
-    _Float16 *const p1h = buf + (PRECISE ? 2 : 1) * PLANE, *const p1l = buf + 3 * PLANE;
+    // planes: ping (p0) and pong (p1)
+    _Float16 *const p0h = buf, *const p1h = buf + PLANE;
     auto load_bias = [&](const float *b, float4 (&o)[CB][4]) {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
@@ -519,26 +507,20 @@ __device__ __forceinline__ void net_forward_wave1(const NetDev &nd, _Float16 *bu
     };
     // rolling weight window, primed with the first WDEPTH k-steps of the tower; fragment (k-step t, cout block cb)
     // lives at [(t * CB + cb) * 64 + lane]
-    half8 wh[WDEPTH][CB], wl[WDEPTH][CB];
-    const half8 *wph = nd.conv_w + lane, *wpl = nd.conv_wl + lane;
+    half8 wh[WDEPTH][CB];
+    const half8 *wph = nd.conv_w + lane;
     const int total_steps = n_layers * KS;
 #pragma unroll
     for (int s = 0; s < WDEPTH; ++s) {
         const int t = s < total_steps ? s : 0;
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            wh[s][cb] = wph[(t * CB + cb) * 64];
-            if (PRECISE) wl[s][cb] = wpl[(t * CB + cb) * 64];
-        }
+        for (int cb = 0; cb < CB; ++cb) wh[s][cb] = wph[(t * CB + cb) * 64];
     }
-    half8 swh[3][CB], swl[3][CB];
+    half8 swh[3][CB];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            swh[s][cb] = nd.stem_w[(s * CB + cb) * 64 + lane];
-            if (PRECISE) swl[s][cb] = nd.stem_wl[(s * CB + cb) * 64 + lane];
-        }
+        for (int cb = 0; cb < CB; ++cb) swh[s][cb] = nd.stem_w[(s * CB + cb) * 64 + lane];
     float4 bias[CB][4];
     load_bias(bias_lds, bias);
     // input planes (board.py:147-154), 4 halves per row, at the start of p1h (the tower writes it only after the stem)
@@ -557,7 +539,6 @@ __device__ __forceinline__ void net_forward_wave1(const NetDev &nd, _Float16 *bu
     for (int i = lane; i < CSF; i += 64) {   // the zero rows of the planes (the input planes occupy the first rows of p1h only)
         p0h[PIX * CSF + i] = (_Float16)0.0f;
         p1h[PIX * CSF + i] = (_Float16)0.0f;
-        if (PRECISE) { p0l[PIX * CSF + i] = (_Float16)0.0f; p1l[PIX * CSF + i] = (_Float16)0.0f; }
     }
     // row geometry: tile ti holds rows 32 ti + r32; rows >= 42 read the zero row and store nothing
     uint32_t rsel2[2][5];
@@ -582,7 +563,7 @@ __device__ __forceinline__ void net_forward_wave1(const NetDev &nd, _Float16 *bu
     auto rsel = [&](int ti, int tap) -> int { return (int)((rsel2[ti][tap >> 1] >> (16 * (tap & 1))) & 0xffffu); };
     // ------------------------------------------------------------------ stem: planes -> p0
     {
-        floatx16 ah[2][CB], al[2][CB];
+        floatx16 ah[2][CB];
         half4 v[2][6];
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
@@ -597,7 +578,7 @@ __device__ __forceinline__ void net_forward_wave1(const NetDev &nd, _Float16 *bu
                 v[ti][i] = *reinterpret_cast<const half4 *>(inp + row * 4);
             }
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) { ah[ti][cb] = acc_from_bias(bias[cb]); al[ti][cb] = floatx16{}; }
+            for (int cb = 0; cb < CB; ++cb) ah[ti][cb] = acc_from_bias(bias[cb]);
         }
 #pragma unroll
         for (int s = 0; s < 3; ++s)
@@ -607,35 +588,29 @@ __device__ __forceinline__ void net_forward_wave1(const NetDev &nd, _Float16 *bu
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { bf[j] = v[ti][2 * s][j]; bf[4 + j] = v[ti][2 * s + 1][j]; }
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    ah[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(swh[s][cb], bf, ah[ti][cb], 0, 0, 0);
-                    if (PRECISE) al[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(swl[s][cb], bf, al[ti][cb], 0, 0, 0);
-                }
+                for (int cb = 0; cb < CB; ++cb) ah[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(swh[s][cb], bf, ah[ti][cb], 0, 0, 0);
             }
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
-                wave1_store<FW, PRECISE>(ah[ti][cb], al[ti][cb], p0h, p0l, rbase[ti] + 32 * cb + 4 * h, real[ti]);
+                wave1_store<FW>(ah[ti][cb], p0h, rbase[ti] + 32 * cb + 4 * h, real[ti]);
     }
     stamp(1);
     // ------------------------------------------------------------------ residual tower
     for (int L = 0; L < n_layers; ++L) {
         const bool second = L & 1;
-        const _Float16 *sh = second ? p1h : p0h, *sl = second ? p1l : p0l;
-        _Float16 *dh = second ? p0h : p1h, *dl = second ? p0l : p1l;
-        floatx16 ah[2][CB], al[2][CB];
+        const _Float16 *sh = second ? p1h : p0h;
+        _Float16 *dh = second ? p0h : p1h;
+        floatx16 ah[2][CB];
         load_bias(bias_lds + FW * (1 + L), bias);
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) { ah[ti][cb] = acc_from_bias(bias[cb]); al[ti][cb] = floatx16{}; }
-        half8 bh[2], bl[2], nh[2], nl[2];
+            for (int cb = 0; cb < CB; ++cb) ah[ti][cb] = acc_from_bias(bias[cb]);
+        half8 bh[2], nh[2];
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
-            bh[ti] = *reinterpret_cast<const half8 *>(sh + rsel(ti, 0));
-            if (PRECISE) bl[ti] = *reinterpret_cast<const half8 *>(sl + rsel(ti, 0));
-        }
+        for (int ti = 0; ti < 2; ++ti) bh[ti] = *reinterpret_cast<const half8 *>(sh + rsel(ti, 0));
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             if (s + 1 < KS) {
@@ -643,35 +618,25 @@ __device__ __forceinline__ void net_forward_wave1(const NetDev &nd, _Float16 *bu
                 for (int ti = 0; ti < 2; ++ti) {
                     const int o = rsel(ti, (s + 1) / KPT) + ((s + 1) % KPT) * 16;
                     nh[ti] = *reinterpret_cast<const half8 *>(sh + o);
-                    if (PRECISE) nl[ti] = *reinterpret_cast<const half8 *>(sl + o);
                 }
             }
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 const half8 cwh = wh[s % WDEPTH][cb];
 #pragma unroll
-                for (int ti = 0; ti < 2; ++ti) {
-                    ah[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh, bh[ti], ah[ti][cb], 0, 0, 0);
-                    if (PRECISE) {
-                        al[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s % WDEPTH][cb], bh[ti], al[ti][cb], 0, 0, 0);
-                        al[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh, bl[ti], al[ti][cb], 0, 0, 0);
-                    }
-                }
+                for (int ti = 0; ti < 2; ++ti) ah[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh, bh[ti], ah[ti][cb], 0, 0, 0);
             }
             {   // refill the window slot just used with k-step (L*KS + s + WDEPTH) of the tower; unconditional
                 // (past the end it re-reads step 0: a branch around the loads would drain vmcnt)
                 int t = L * KS + s + WDEPTH;
                 t = t < total_steps ? t : 0;
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    wh[s % WDEPTH][cb] = wph[(t * CB + cb) * 64];
-                    if (PRECISE) wl[s % WDEPTH][cb] = wpl[(t * CB + cb) * 64];
-                }
+                for (int cb = 0; cb < CB; ++cb) wh[s % WDEPTH][cb] = wph[(t * CB + cb) * 64];
             }
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti) { bh[ti] = nh[ti]; if (PRECISE) bl[ti] = nl[ti]; }
+            for (int ti = 0; ti < 2; ++ti) bh[ti] = nh[ti];
         }
-        if (second) {   // + block input (lives in dh/dl): identity MFMAs keep it exact in both accumulators
+        if (second) {   // + block input (lives in dh): identity MFMAs add it exactly
             half8 idf[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -685,18 +650,13 @@ __device__ __forceinline__ void net_forward_wave1(const NetDev &nd, _Float16 *bu
                     const half8 xh0 = *reinterpret_cast<const half8 *>(dh + o), xh1 = *reinterpret_cast<const half8 *>(dh + o + 16);
                     ah[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[0], xh0, ah[ti][cb], 0, 0, 0);
                     ah[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[1], xh1, ah[ti][cb], 0, 0, 0);
-                    if (PRECISE) {
-                        const half8 xl0 = *reinterpret_cast<const half8 *>(dl + o), xl1 = *reinterpret_cast<const half8 *>(dl + o + 16);
-                        al[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[0], xl0, al[ti][cb], 0, 0, 0);
-                        al[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[1], xl1, al[ti][cb], 0, 0, 0);
-                    }
                 }
         }
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
-                wave1_store<FW, PRECISE>(ah[ti][cb], al[ti][cb], dh, dl, rbase[ti] + 32 * cb + 4 * h, real[ti]);
+                wave1_store<FW>(ah[ti][cb], dh, rbase[ti] + 32 * cb + 4 * h, real[ti]);
         if (L < 6) stamp(2 + L);
     }
     stamp(8);
@@ -708,22 +668,16 @@ __device__ __forceinline__ void net_forward_wave1(const NetDev &nd, _Float16 *bu
         float o0[2], o1[2], o2[2];
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
-            floatx16 a = {}, b = {};
+            floatx16 a = {};
 #pragma unroll
             for (int s = 0; s < KPT; ++s) {
                 const half8 hwh = nd.head_w[s * 64 + lane];
                 const half8 xh = *reinterpret_cast<const half8 *>(p0h + rbase[ti] + 16 * s + 8 * h);
                 a = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwh, xh, a, 0, 0, 0);
-                if (PRECISE) {
-                    const half8 hwl = nd.head_wl[s * 64 + lane];
-                    const half8 xl = *reinterpret_cast<const half8 *>(p0l + rbase[ti] + 16 * s + 8 * h);
-                    b = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwl, xh, b, 0, 0, 0);
-                    b = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwh, xl, b, 0, 0, 0);
-                }
             }
-            o0[ti] = lrelu(a[0] + (PRECISE ? b[0] * LO_INV : 0.0f) + hb0);
-            o1[ti] = lrelu(a[1] + (PRECISE ? b[1] * LO_INV : 0.0f) + hb1);
-            o2[ti] = lrelu(a[2] + (PRECISE ? b[2] * LO_INV : 0.0f) + hb2);
+            o0[ti] = lrelu(a[0] + hb0);
+            o1[ti] = lrelu(a[1] + hb1);
+            o2[ti] = lrelu(a[2] + hb2);
         }
         // every lane has read the tower output and p1 is dead: the head planes may overwrite p1h
 #pragma unroll
@@ -1041,20 +995,277 @@ __device__ __forceinline__ void net_forward_wave16(const NetDev &nd, _Float16 *b
     stamp(10);
 }
 
+// ------------------------------------------------------------------------------------------------
+// net_forward_wave16p: the reference-precision forward (C4_NET_F32X3, see net_forward_wave1 for the
+// arithmetic: x ~= hi + lo / 2^11 in fp16, hi*hi into one accumulator, hi*lo + lo*hi into a second one) on
+// the 16-row tiles of net_forward_wave16: 9 taps x 3 row tiles x 2 cout tiles x 3 = 162 MFMAs of 16 cycles per
+// layer instead of 108 of 32, four planes (ping/pong x hi/lo) of 43 rows x 96 bytes, the hi and lo weight
+// fragments of a tap stream from L2 through a rolling window of three taps (the tower's taps are one linear
+// sequence in memory).  Same accumulation per output element as net_forward_wave1<32, true>.
+// ------------------------------------------------------------------------------------------------
+constexpr int WTAPS = 3;   // taps of weights in flight (divides 9: a tap's window slot is t % 3 in every layer)
+
+__device__ __forceinline__ void store16p(const floatx4 &hi, const floatx4 &lo, _Float16 *dh, _Float16 *dl, int off, bool real)
+{
+    half4 oh, ol;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float y = lrelu(hi[i] + lo[i] * LO_INV);
+        const _Float16 yh = (_Float16)y;
+        oh[i] = yh;
+        ol[i] = (_Float16)((y - (float)yh) * LO_SCALE);
+    }
+    if (real) {
+        *reinterpret_cast<half4 *>(dh + off) = oh;
+        *reinterpret_cast<half4 *>(dl + off) = ol;
+    }
+}
+
+__device__ __forceinline__ void net_forward_wave16p(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds,
+                                                    const uint16_t *tab, uint64_t b0, uint64_t b1, float *__restrict__ values,
+                                                    float *__restrict__ priors, int out, unsigned long long *stamps = nullptr)
+{
+    int lane_ = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_));     // keep lane-derived addresses out of a persistent caller's loop (see net_forward_wave16)
+    const int lane = lane_;
+    const int n = lane & 15, g = lane >> 4;
+    auto stamp = [&](int i) { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
+    const int n_layers = 2 * nd.n_res;
+    _Float16 *const p0h = buf, *const p0l = buf + PLANE16, *const p1h = buf + 2 * PLANE16, *const p1l = buf + 3 * PLANE16;
+    // rolling weight window: fragment (tap T of the tower, cout tile ct) at [(T * 2 + ct) * 64 + lane], hi and lo
+    half8 wh[WTAPS][2], wl[WTAPS][2];
+    const half8 *wph = nd.conv_w16 + lane, *wpl = nd.conv_w16l + lane;
+    const int total_taps = n_layers * 9;
+#pragma unroll
+    for (int t = 0; t < WTAPS; ++t) {
+        const int T = t < total_taps ? t : 0;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) { wh[t][ct] = wph[(T * 2 + ct) * 64]; wl[t][ct] = wpl[(T * 2 + ct) * 64]; }
+    }
+    half8 swh[4], swl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { swh[i] = nd.stem_w16[i * 64 + lane]; swl[i] = nd.stem_w16l[i * 64 + lane]; }
+    uint32_t tb[TAB16 / 2];
+    {
+        const uint4 *t4 = reinterpret_cast<const uint4 *>(tab + lane * TAB16);
+#pragma unroll
+        for (int i = 0; i < TAB16 / 8; ++i) { const uint4 v = t4[i]; tb[4 * i] = v.x; tb[4 * i + 1] = v.y; tb[4 * i + 2] = v.z; tb[4 * i + 3] = v.w; }
+    }
+    auto tof = [&](int idx) -> int { return (int)((tb[idx >> 1] >> (16 * (idx & 1))) & 0xffffu); };
+    // input planes (board.py:147-154), 4 halves per row, at the start of p1h (the tower writes it only after the stem)
+    _Float16 *inp = p1h;
+    if (lane <= PIX) {
+        half4 v = {};
+        if (lane < PIX) {
+            const int y = lane / 7, x = lane - y * 7;
+            const int bit = x * 7 + (5 - y);
+            v[0] = (_Float16)((__popcll(b0 | b1) & 1) ? 0.0f : 1.0f);
+            v[1] = (_Float16)(float)((b0 >> bit) & 1);
+            v[2] = (_Float16)(float)((b1 >> bit) & 1);
+        }
+        *reinterpret_cast<half4 *>(inp + lane * 4) = v;   // lane == PIX: the zero row of the planes
+    }
+    if (lane < CS16) {
+        p0h[PIX * CS16 + lane] = (_Float16)0.0f; p0l[PIX * CS16 + lane] = (_Float16)0.0f;
+        p1h[PIX * CS16 + lane] = (_Float16)0.0f; p1l[PIX * CS16 + lane] = (_Float16)0.0f;
+    }
+    bool real[RT16];
+    int rbase[RT16];
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt) {
+        real[rt] = 16 * rt + n < PIX;
+        rbase[rt] = (real[rt] ? 16 * rt + n : PIX) * CS16;
+    }
+    auto bias4 = [&](const float *b, int ct) -> floatx4 {
+        const float4 v = *reinterpret_cast<const float4 *>(b + 16 * ct + 4 * g);
+        return floatx4{v.x, v.y, v.z, v.w};
+    };
+    const floatx4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    // ------------------------------------------------------------------ stem (0/1 inputs: two MFMAs per step)
+    {
+        floatx4 ah[RT16][2], al[RT16][2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const floatx4 bv = bias4(bias_lds, ct);
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) { ah[rt][ct] = bv; al[rt][ct] = zero4; }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) {
+                const half4 va = *reinterpret_cast<const half4 *>(inp + tof(27 + rt * 4 + s * 2));
+                const half4 vb = *reinterpret_cast<const half4 *>(inp + tof(27 + rt * 4 + s * 2 + 1));
+                half8 bf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bf[j] = va[j]; bf[4 + j] = vb[j]; }
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    ah[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[s * 2 + ct], bf, ah[rt][ct], 0, 0, 0);
+                    al[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[s * 2 + ct], bf, al[rt][ct], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) store16p(ah[rt][ct], al[rt][ct], p0h, p0l, rbase[rt] + 16 * ct + 4 * g, real[rt]);
+    }
+    stamp(1);
+    // ------------------------------------------------------------------ residual tower
+    for (int L = 0; L < n_layers; ++L) {
+        const bool second = L & 1;
+        const _Float16 *sh = second ? p1h : p0h, *sl = second ? p1l : p0l;
+        _Float16 *dh = second ? p0h : p1h, *dl = second ? p0l : p1l;
+        floatx4 ah[RT16][2], al[RT16][2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const floatx4 bv = bias4(bias_lds + F * (1 + L), ct);
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) { ah[rt][ct] = bv; al[rt][ct] = zero4; }
+        }
+        half8 bh[RT16], bl[RT16], nh[RT16], nl[RT16];
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt) {
+            bh[rt] = *reinterpret_cast<const half8 *>(sh + tof(rt * 9));
+            bl[rt] = *reinterpret_cast<const half8 *>(sl + tof(rt * 9));
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t + 1 < 9) {
+#pragma unroll
+                for (int rt = 0; rt < RT16; ++rt) {
+                    nh[rt] = *reinterpret_cast<const half8 *>(sh + tof(rt * 9 + t + 1));
+                    nl[rt] = *reinterpret_cast<const half8 *>(sl + tof(rt * 9 + t + 1));
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const half8 cwh = wh[t % WTAPS][ct], cwl = wl[t % WTAPS][ct];
+#pragma unroll
+                for (int rt = 0; rt < RT16; ++rt) {
+                    ah[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cwh, bh[rt], ah[rt][ct], 0, 0, 0);
+                    al[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cwl, bh[rt], al[rt][ct], 0, 0, 0);
+                    al[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cwh, bl[rt], al[rt][ct], 0, 0, 0);
+                }
+            }
+            {   // refill the window slot just used with tap (L*9 + t + WTAPS) of the tower; unconditional (past the end
+                // it re-reads tap 0: a branch around the loads would drain vmcnt)
+                int T = L * 9 + t + WTAPS;
+                T = T < total_taps ? T : 0;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) { wh[t % WTAPS][ct] = wph[(T * 2 + ct) * 64]; wl[t % WTAPS][ct] = wpl[(T * 2 + ct) * 64]; }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) { bh[rt] = nh[rt]; bl[rt] = nl[rt]; }
+        }
+        if (second) {   // + block input (lives in dh/dl): identity MFMAs keep it exact in both accumulators
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) {
+                const half8 xh = *reinterpret_cast<const half8 *>(dh + rbase[rt] + 8 * g);
+                const half8 xl = *reinterpret_cast<const half8 *>(dl + rbase[rt] + 8 * g);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    half8 idf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) idf[j] = (_Float16)((8 * g + j) == 16 * ct + n ? 1.0f : 0.0f);
+                    ah[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(idf, xh, ah[rt][ct], 0, 0, 0);
+                    al[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(idf, xl, al[rt][ct], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) store16p(ah[rt][ct], al[rt][ct], dh, dl, rbase[rt] + 16 * ct + 4 * g, real[rt]);
+        if (L < 6) stamp(2 + L);
+    }
+    stamp(8);
+    // ------------------------------------------------------------------ 1x1 head convs
+    float *hs = reinterpret_cast<float *>(p1h);   // [HSTR] fp32 (p1 is free)
+    {
+        const half8 hwh = nd.head_w16[lane], hwl = nd.head_w16l[lane];
+        const float hb0 = nd.head_b[0], hb1 = nd.head_b[1], hb2 = nd.head_b[2];
+        floatx4 a[RT16], b[RT16];
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt) {
+            const half8 xh = *reinterpret_cast<const half8 *>(p0h + rbase[rt] + 8 * g);
+            const half8 xl = *reinterpret_cast<const half8 *>(p0l + rbase[rt] + 8 * g);
+            a[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwh, xh, zero4, 0, 0, 0);
+            b[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwl, xh, zero4, 0, 0, 0);
+            b[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwh, xl, b[rt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt) {
+            const int r = 16 * rt + n;
+            if (g == 0 && r < PIX) {
+                hs[0 * PIX + r] = lrelu(a[rt][0] + b[rt][0] * LO_INV + hb0);
+                hs[1 * PIX + r] = lrelu(a[rt][1] + b[rt][1] * LO_INV + hb1);
+                hs[2 * PIX + r] = lrelu(a[rt][2] + b[rt][2] * LO_INV + hb2);
+            }
+        }
+        if (lane < 2) hs[HEADV + lane] = 0.0f;   // pad 126,127
+    }
+    stamp(9);
+    // ------------------------------------------------------------------ MLP heads (fp32 VALU), as in net_forward_block
+    {
+        const float *vt_b = reinterpret_cast<const float *>(mlp + VT_F4 + PT_F / 4);   // fc_b | vout_w | pfc_b
+        const float *pt = reinterpret_cast<const float *>(mlp + VT_F4);
+        const float4 *hA4 = reinterpret_cast<const float4 *>(hs);
+        float v0 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 11; ++q) {
+            const float4 wv = mlp[q * 64 + lane];
+            const float4 xa = hA4[q];
+            v0 += wv.x * xa.x + wv.y * xa.y + wv.z * xa.z + wv.w * xa.w;
+        }
+        const int seg = lane >> 3;
+        const float *hpA = hs + PIX + seg * 11;
+        float l0 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 11; ++c) {
+            const float wv = pt[c * 64 + lane];      // zero where seg*11 + c >= 84 or (lane & 7) == 7
+            const int cc = seg * 11 + c < 2 * PIX ? c : 2 * PIX - 1 - seg * 11;
+            l0 += wv * hpA[cc];
+        }
+        l0 += dppf<0x128>(l0);
+#pragma unroll
+        for (int m = 16; m <= 32; m <<= 1) l0 += __shfl_xor(l0, m, 64);
+        const float fb = vt_b[lane], vw = vt_b[64 + lane], pb = vt_b[128 + lane];
+        const bool is_pol = lane < 7;
+        const float a = v0 + fb;
+        const float lg = l0 + pb;
+        const float rs = sum16(lane < PIX ? vw * lrelu(a) : 0.0f);               // model.py:83-85
+        const float vsum = readlane_f(rs, 0) + readlane_f(rs, 16) + readlane_f(rs, 32);
+        const float value = (tanhf(vsum + nd.vout_b) + nd.w1) * nd.w2;           // model.py:86-88
+        const float mx = max8(is_pol ? lg : -INFINITY);
+        const float e = is_pol ? expf(lg - mx) : 0.0f;
+        const float sum = sum8(e);
+        if (lane == 0) values[out] = value;
+        if (is_pol) priors[(size_t)out * 7 + lane] = e / sum;
+    }
+    stamp(10);
+}
+
 // net mode of a NetDev, as the kernels are specialised
 constexpr int NETMODE_F32_F16 = 0;    // 32 filters, fp16 storage: net_forward_wave16 / net_forward_block
 constexpr int NETMODE_F32_PRECISE = 1;
 constexpr int NETMODE_F64 = 2;        // 64 filters, fp16 storage, one position per pass
 template <int MODE>
-__device__ __forceinline__ void net_forward_wave1_mode(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds, uint64_t b0,
-                                                       uint64_t b1, float *__restrict__ values, float *__restrict__ priors, int out,
-                                                       unsigned long long *stamps = nullptr)
+__device__ __forceinline__ void net_forward_wave1_mode(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds,
+                                                       const uint16_t *tab, uint64_t b0, uint64_t b1, float *__restrict__ values,
+                                                       float *__restrict__ priors, int out, unsigned long long *stamps = nullptr)
 {
-    if (MODE == NETMODE_F64) net_forward_wave1<64, false>(nd, buf, mlp, bias_lds, b0, b1, values, priors, out, stamps);
-    else net_forward_wave1<32, true>(nd, buf, mlp, bias_lds, b0, b1, values, priors, out, stamps);
+    if (MODE == NETMODE_F64) net_forward_wave1<64>(nd, buf, mlp, bias_lds, b0, b1, values, priors, out, stamps);
+    else if (MODE == NETMODE_F32_PRECISE) net_forward_wave16p(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, stamps);
+    else net_forward_wave16(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, stamps);
 }
+// halves of private LDS a wave needs for its planes in each mode
+template <int MODE> struct WaveBuf {
+    static constexpr int HALVES = MODE == NETMODE_F64 ? 2 * WACT : (MODE == NETMODE_F32_PRECISE ? 4 * PLANE16 : 2 * PLANE16);
+};
 
-constexpr int BIAS_LDS_FLOATS = 32 * (1 + 128);   // 16.5 KB: stem + conv biases of up to 64 residual blocks at 32 filters, 32 at 64
+constexpr int BIAS_LDS_FLOATS = 32 * (1 + 32);    // 4.2 KB: stem + conv biases of up to 16 residual blocks at 32 filters, 7 at 64
 // cooperative fill of the LDS bias copy by the whole workgroup (the caller synchronises afterwards)
 __device__ __forceinline__ void stage_bias_lds(const NetDev &nd, float *bias_lds)
 {

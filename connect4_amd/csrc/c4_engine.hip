@@ -576,14 +576,22 @@ template <> __device__ __forceinline__ void store_plane<hip_bfloat16>(void *p, s
 // DevT: `const Dev` (kernel argument, held in SGPRs) or a constant-address-space view of the engine's device
 // copy: the wave kernel reads each field with a scalar load where it is used instead of holding ~70
 // argument SGPRs (most of them spilled to VGPR lanes) for its whole lifetime.
-template <int EVAL, bool STAMPS = true, bool LDS_STATE = false, bool WAVE_SYNC = false, bool PATH_KEPT = false, class DevT = const Dev>
+// SPLIT (c4_selfplay_split_kernel: tree waves and network waves): a slot that needs the evaluator posts its leaf
+// (`*req = REQ_POSTED`) and idles INSIDE the loop while the other slots of the wave keep walking: at the top of
+// every iteration it looks at `*req` and applies the answer once a network wave has written REQ_ANSWERED.  The call
+// ends at the deadline; a slot still waiting then carries its leaf into the next launch.
+constexpr uint32_t REQ_IDLE = 0, REQ_POSTED = 1, REQ_TAKEN = 2, REQ_ANSWERED = 3;
+template <int EVAL, bool STAMPS = true, bool LDS_STATE = false, bool WAVE_SYNC = false, bool PATH_KEPT = false, class DevT = const Dev,
+          bool SPLIT = false>
 __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, const int gl,
                                           PathEntry (*s_path)[MAX_DEPTH], Rec (*s_l1)[GROUP],
                                           const void *__restrict__ values_in,
                                           const void *__restrict__ priors_in, void *__restrict__ planes_out,
                                           uint64_t *leaf_out, SlotMem *sm = nullptr, const int ai_lds = 0,
-                                          uint32_t *wg_stats = nullptr, const unsigned long long deadline = 0)
+                                          uint32_t *wg_stats = nullptr, const unsigned long long deadline = 0,
+                                          uint32_t *req = nullptr)
 {
+    static_assert(!SPLIT || (WAVE_SYNC && LDS_STATE && PATH_KEPT), "the split kernel keeps slot states and paths in LDS");
     if (leaf_out && lane < 2) leaf_out[lane] = 0;
     if (g >= d.slot_hi) return;
     if (LDS_STATE) {
@@ -630,6 +638,10 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
     // own for the whole launch (no global round trip between emitting a leaf and applying its answer)
     bool path_lds = (EVAL == C4_EVAL_CENTRE) || PATH_KEPT;
     bool fresh_eval = false;                    // the answer came from the evaluator: remember it
+    if (SPLIT && pend >= 0) {
+        if (*(volatile uint32_t *)req != REQ_ANSWERED) return;   // its leaf is still with the network waves
+        if (lane == 0) *(volatile uint32_t *)req = REQ_IDLE;
+    }
     if (pend >= 0) {
         leaf0 = LDS_STATE ? sm->leaf0 : d.leaf_c0[g];
         leaf1 = LDS_STATE ? sm->leaf1 : d.leaf_c1[g];
@@ -667,7 +679,21 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
     bool l1_valid = false;
     int inner = 0;
     const unsigned long long wave_mask0 = WAVE_SYNC ? __builtin_amdgcn_ballot_w64(true) : 0ull;
+    bool waiting = false;   // SPLIT: the leaf is with the network waves
     for (;;) {
+        if (SPLIT) {
+            if (__builtin_amdgcn_ballot_w64(!waiting) == 0) __builtin_amdgcn_s_sleep(4);   // nobody in this wave can walk
+            if (waiting) {
+                if ((long long)(__builtin_amdgcn_s_memtime() - deadline) > 0) { has_leaf = 1; break; }
+                if (*(volatile uint32_t *)req != REQ_ANSWERED) continue;
+                ev_value = (double)((const volatile float *)values_in)[ai];
+                ev_prior = lane < 7 ? (double)((const volatile float *)priors_in)[(size_t)ai * 7 + lane] : 0.0;
+                if (lane == 0) *(volatile uint32_t *)req = REQ_IDLE;
+                waiting = false;
+                apply_now = true;
+                fresh_eval = d.cache != nullptr;
+            }
+        }
         // ---------------------------------------------------------------- evaluate_node + expand + backup
         if (apply_now) {
             apply_now = false;
@@ -796,6 +822,16 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                     continue;
                 }
             }
+            if (SPLIT) {   // hand the leaf to the network waves now: the other slots of this wave walk on
+                if (lane == 0) {
+                    sm->leaf0 = leaf0;
+                    sm->leaf1 = leaf1;
+                    lds_fence();
+                    *(volatile uint32_t *)req = REQ_POSTED;
+                }
+                waiting = true;
+                continue;
+            }
             has_leaf = 1;
             break;
         }
@@ -884,9 +920,11 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
 
         // bound the launch: at most max_inner evaluator-free simulations per launch
         // a neighbour needs the network, or the launch's time quantum is over
-        if (WAVE_SYNC && !resume && (__builtin_amdgcn_ballot_w64(true) != wave_mask0 ||
+        if (SPLIT) {
+            if ((long long)(__builtin_amdgcn_s_memtime() - deadline) > 0) break;
+        } else if (WAVE_SYNC && !resume && (__builtin_amdgcn_ballot_w64(true) != wave_mask0 ||
                                      ((inner & (C4_DEADLINE_EVERY - 1)) == 0 && (long long)(__builtin_amdgcn_s_memtime() - deadline) > 0))) break;
-        if (!resume && (inner >= d.max_inner || levels_left <= 0 ||
+        if (!SPLIT && !resume && (inner >= d.max_inner || levels_left <= 0 ||
                         (!WAVE_SYNC && d.time_budget > 0 && inner > 0 && (long long)(__builtin_amdgcn_s_memtime() - t_begin) > d.time_budget))) {
             st.capped += 1;
             break;
@@ -1128,6 +1166,16 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
         }
         if (!PATH_KEPT)
             for (uint32_t i = lane; i < depth; i += GROUP) gpath[i] = s_path[gl][i];
+        if (SPLIT) {   // hand the leaf to the network waves now: the other slots of this wave walk on
+            if (lane == 0) {
+                sm->leaf0 = leaf0;
+                sm->leaf1 = leaf1;
+                lds_fence();
+                *(volatile uint32_t *)req = REQ_POSTED;
+            }
+            waiting = true;
+            continue;
+        }
         has_leaf = 1;
         break;
     }
@@ -1474,6 +1522,172 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------
+// c4_selfplay_split_kernel<TS, MODE>: tree waves and network waves.
+// The wave-autonomous kernel above gives every wave 2 slots (16 of its 64 lanes walk trees) and lets it stop
+// walking whenever one of them needs the network.  Here the first wave on every SIMD is a TREE wave that owns
+// TS/4 slots (4 at 16 slots per CU: every tree instruction serves twice the lanes) and never runs the network;
+// the second wave on every SIMD is a NETWORK wave.  A slot that misses the evaluation cache posts its leaf in LDS
+// and steps out of the wave's loop, the other slots of the wave walk on; any idle network wave claims the request
+// (compare-and-swap on the slot's request word), runs the one-position forward and marks the request answered; the
+// waiting slot sees that at the top of its next loop iteration and applies the answer.
+// Launch end: tree waves stop at the deadline; the network waves drain every posted request before they leave,
+// so between launches "has a leaf" means "answered", exactly as with the wave kernel (the two are interchangeable
+// launch by launch and play the same games).
+// ------------------------------------------------------------------------------------------
+template <int TS, int MODE, int TW = 4>
+__global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(const Dev *d_dev, c4net::NetDev nd, float *__restrict__ values,
+                                                                            float *__restrict__ priors, int n_steps)
+{
+    using namespace c4net;
+    const_dev &d = *(const_dev *)d_dev;
+    constexpr int NW = NWAVES - TW;           // tree waves, network waves (TW = 4: one of each per SIMD)
+    constexpr int SPW = (TS + TW - 1) / TW;   // slots per tree wave (at most)
+    static_assert(TW >= 1 && NW >= 1 && SPW >= 1 && SPW <= 8 && TS <= 64, "slots per workgroup");
+    constexpr int WBUF = WaveBuf<MODE>::HALVES;
+    __shared__ __attribute__((aligned(16))) _Float16 act[NW][WBUF];   // planes of the network waves
+    __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
+    __shared__ SlotMem smem[TS];
+    __shared__ float s_val[TS];
+    __shared__ float s_pri[TS * 7];
+    __shared__ uint32_t s_stats[N_STATS];
+    __shared__ __attribute__((aligned(16))) float s_bias[BIAS_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab16[(MODE != NETMODE_F64) ? 64 * TAB16 : 8];
+    __shared__ __attribute__((aligned(16))) PathEntry s_path[TS][MAX_DEPTH];   // every slot's descent path, for the whole launch
+    __shared__ __attribute__((aligned(16))) Rec s_l1[TS][GROUP];               // every slot's root block
+    __shared__ uint32_t s_req[TS];     // REQ_* of the slot's leaf
+    __shared__ uint32_t s_simd[4];     // waves seen per SIMD (role assignment)
+    __shared__ uint32_t s_tree_done;   // tree waves past the deadline
+    const int slot0 = blockIdx.x * TS;
+    // ---- launch prologue: slot states, pending answers and the MLP tables, global -> LDS
+    if (threadIdx.x < TS) {
+        const int p = threadIdx.x, g = slot0 + p;
+        SlotMem m = {};
+        m.flags = SlotMem::pack(SLOT_PARKED, 0, 0);
+        if (g < d.G) {
+            m.root0 = d.root_c0[g]; m.root1 = d.root_c1[g]; m.leaf0 = d.leaf_c0[g]; m.leaf1 = d.leaf_c1[g];
+            m.gid = d.game_id[g]; m.sims = d.sims_done[g]; m.nalloc = d.n_alloc[g]; m.pend = d.pending[g];
+            m.pdepth = d.pending_depth[g]; m.pinfo = d.pending_info[g];
+            m.ply = d.ply[g]; m.flags = SlotMem::pack(d.state[g], d.has_leaf[g], d.need_root[g]);
+            m.root_w = *(const double *)(d.pool + (size_t)g * d.cap * (BLOCK_BYTES / 8));   // Rec::w of node 0
+        }
+        smem[p] = m;
+        s_req[p] = m.has_leaf() ? REQ_ANSWERED : REQ_IDLE;   // a leaf carried over from the previous launch has its answer
+    }
+    if (threadIdx.x < N_STATS) s_stats[threadIdx.x] = 0;
+    if (threadIdx.x < 4) s_simd[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_tree_done = 0;
+    for (int i = threadIdx.x; i < TS * 8; i += NTHREADS) {   // answers of the previous launch
+        const int p = i >> 3, k = i & 7;
+        const bool ok = slot0 + p < d.G;
+        if (k == 7) s_val[p] = ok ? values[slot0 + p] : 0.0f;
+        else s_pri[p * 7 + k] = ok ? priors[(size_t)(slot0 + p) * 7 + k] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
+    stage_bias_lds(nd, s_bias);
+    if (MODE != NETMODE_F64 && threadIdx.x < 64) build_tab16(s_tab16, threadIdx.x);
+    for (int i = threadIdx.x; i < TS * MAX_DEPTH; i += NTHREADS) {   // paths of leaves pending from the previous launch
+        const int p = i / MAX_DEPTH, k = i - p * MAX_DEPTH;
+        if (slot0 + p < d.G) s_path[p][k] = d.path[(size_t)(slot0 + p) * MAX_DEPTH + k];
+    }
+    __syncthreads();
+    // ---- roles: HW_ID.SIMD_ID says where the wave runs; the first wave to register on a SIMD walks trees
+    const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3;   // HW_REG_HW_ID bits [5:4]
+    int rank = 0;
+    if ((threadIdx.x & 63) == 0) rank = (int)atomicAdd(&s_simd[simd], 1u);
+    rank = __builtin_amdgcn_readfirstlane(rank);
+    __syncthreads();
+    // (a placement other than two waves per SIMD -- not seen, the kernel's VGPR count allows no other -- falls back to
+    // roles by wave index: a tree wave index nobody holds would leave its slots unserved)
+    const bool even = TW == 4 && s_simd[0] == 2 && s_simd[1] == 2 && s_simd[2] == 2 && s_simd[3] == 2;
+    const int wv = threadIdx.x >> 6;
+    const bool is_tree = even ? rank == 0 : wv < TW;
+    const int role_idx = even ? simd : (wv < TW ? wv : wv - TW);
+    const unsigned long long t_launch = __builtin_amdgcn_s_memtime();
+    const unsigned long long quantum = (unsigned long long)n_steps * (unsigned long long)(d.time_budget > 0 ? d.time_budget : 80000);
+    unsigned long long t_busy = 0, n_pass = 0;   // diagnostic (C4_TREE_STAMPS=1)
+    if (is_tree) {
+        const int tw = role_idx;   // tree wave index
+        while (__builtin_amdgcn_s_memtime() - t_launch < quantum) {
+            const unsigned long long ta = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));   // keep lane-derived addresses of the call out of the loop's live ranges
+            const int lane = tid & (GROUP - 1);
+            const int grp = (tid & 63) / GROUP;
+            const int sl = tw + TW * grp;         // slot of this 8-lane group inside the workgroup
+            bool runnable = false;
+            if (grp < SPW && sl < TS) {
+                const uint32_t fl = smem[sl].flags;
+                runnable = (fl & 0xffu) == SLOT_ACTIVE && (((fl >> 8) & 0xffu) == 0 || *(volatile uint32_t *)&s_req[sl] == REQ_ANSWERED);
+            }
+            if (__builtin_amdgcn_ballot_w64(runnable) == 0) {   // every slot waits for the network (or is parked)
+                __builtin_amdgcn_s_sleep(8);
+                continue;
+            }
+            if (grp < SPW && sl < TS)
+                tree_step<C4_EVAL_EXTERNAL_F32, false, true, true, true, const_dev, true>(d, slot0 + sl, lane, sl, s_path, s_l1, s_val, s_pri, nullptr,
+                                                                                          nullptr, &smem[sl], sl, s_stats, t_launch + quantum,
+                                                                                          &s_req[sl]);
+            lds_fence();
+            if (d.has_stamps) t_busy += __builtin_amdgcn_s_memtime() - ta;
+        }
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s_tree_done, 1u);
+    } else {
+        const int nw = role_idx;   // network wave index: its planes
+        const int lw = threadIdx.x & 63;
+        for (;;) {
+            const uint32_t done = *(volatile uint32_t *)&s_tree_done;   // read BEFORE the requests: no post can follow a full count
+            const uint32_t r = lw < TS ? *(volatile uint32_t *)&s_req[lw] : REQ_IDLE;
+            unsigned long long m = __builtin_amdgcn_ballot_w64(r == REQ_POSTED);
+            if (m == 0) {
+                if (done == (uint32_t)TW) break;
+                __builtin_amdgcn_s_sleep(4);
+                continue;
+            }
+            // start looking at a different slot on every network wave, so that they do not race for the same request
+            const int rot = (nw * TS) / NW;
+            const unsigned long long mr = ((m >> rot) | (m << (TS - rot))) & ((TS == 64) ? ~0ull : ((1ull << TS) - 1));
+            int c = (__builtin_ctzll(mr) + rot) % TS;
+            c = __builtin_amdgcn_readfirstlane(c);
+            int ok = 0;
+            if (lw == 0) ok = atomicCAS(&s_req[c], REQ_POSTED, REQ_TAKEN) == REQ_POSTED;
+            ok = __builtin_amdgcn_readfirstlane(ok);
+            if (!ok) continue;
+            const unsigned long long ta = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
+            net_forward_wave1_mode<MODE>(nd, &act[nw][0], mlp, s_bias, s_tab16, smem[c].leaf0, smem[c].leaf1, s_val, s_pri, c);
+            lds_fence();   // the answer is in LDS before the request word says so
+            if (lw == 0) *(volatile uint32_t *)&s_req[c] = REQ_ANSWERED;
+            if (d.has_stamps) { t_busy += __builtin_amdgcn_s_memtime() - ta; n_pass += 1; }
+        }
+    }
+    if (d.has_stamps && blockIdx.x < 128 && (threadIdx.x & 63) == 0) {   // per wave: busy cycles (tree waves 0..3, network waves 8..11 | passes << 48)
+        d.cold->stamps[blockIdx.x * 16 + (is_tree ? 0 : 8) + role_idx] = t_busy | (n_pass << 48);
+        d.cold->stamps[blockIdx.x * 16 + (is_tree ? 4 : 12) + role_idx] = (unsigned long long)simd | ((unsigned long long)even << 8);
+    }
+    __syncthreads();
+    // ---- launch epilogue: LDS -> global
+    for (int i = threadIdx.x; i < TS * MAX_DEPTH; i += NTHREADS) {   // paths of the leaves whose answers wait for the next launch
+        const int p = i / MAX_DEPTH, k = i - p * MAX_DEPTH;
+        if (slot0 + p < d.G && smem[p].has_leaf()) d.path[(size_t)(slot0 + p) * MAX_DEPTH + k] = s_path[p][k];
+    }
+    if (threadIdx.x < TS && slot0 + threadIdx.x < d.G) {
+        const int p = threadIdx.x, g = slot0 + p;
+        const SlotMem m = smem[p];
+        d.root_c0[g] = m.root0; d.root_c1[g] = m.root1; d.leaf_c0[g] = m.leaf0; d.leaf_c1[g] = m.leaf1;
+        d.game_id[g] = m.gid; d.sims_done[g] = m.sims; d.n_alloc[g] = m.nalloc; d.pending[g] = m.pend;
+        d.pending_depth[g] = m.pdepth; d.pending_info[g] = m.pinfo; d.need_root[g] = m.need_root();
+        d.ply[g] = m.ply; d.state[g] = m.state(); d.has_leaf[g] = m.has_leaf() ? 1 : 0;
+    }
+    if (threadIdx.x < N_STATS) d.stats[(size_t)slot0 * N_STATS + threadIdx.x] += s_stats[threadIdx.x];
+    for (int i = threadIdx.x; i < TS * 8; i += NTHREADS) {
+        const int p = i >> 3, k = i & 7;
+        if (slot0 + p < d.G) {
+            if (k == 7) values[slot0 + p] = s_val[p];
+            else priors[(size_t)(slot0 + p) * 7 + k] = s_pri[p * 7 + k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------
 __global__ void c4_reset_kernel(Dev d, const uint64_t *c0, const uint64_t *c1, int n_active)
@@ -1756,7 +1970,8 @@ struct c4_engine {
     int64_t *export_scratch;              // device: [0] games, [1] positions of the last export, [2..] per-game offsets
     int64_t launches;
     int fused_slots;      // slots per workgroup of the fused self-play kernel (16 or 32)
-    int fused_wave;       // 1: wave-autonomous fused kernel (c4_selfplay_wave_kernel)
+    int fused_wave;       // 1: wave-autonomous fused kernel (c4_selfplay_wave_kernel); 2: tree waves + network waves (c4_selfplay_split_kernel)
+    int split_tw;         // tuning aid (C4_SPLIT_TW): tree waves of the split kernel at 16 slots per workgroup
     int tape_games;
     double *tape_noise, *tape_u;
     char err[512];
@@ -1881,7 +2096,9 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
         e->fused_slots = ((cfg->n_slots + 31) / 32 >= cus) ? 32 : 16;
         e->fused_wave = 1;   // wave-autonomous kernel; C4_FUSED_MODE=block selects the workgroup-synchronous one
-        if (const char *fm = getenv("C4_FUSED_MODE")) e->fused_wave = strcmp(fm, "block") != 0;
+        if (const char *fm = getenv("C4_FUSED_MODE")) e->fused_wave = strcmp(fm, "block") == 0 ? 0 : (strcmp(fm, "split") == 0 ? 2 : 1);
+        e->split_tw = 4;
+        if (const char *tw = getenv("C4_SPLIT_TW")) e->split_tw = atoi(tw);
         if (const char *fs = getenv("C4_FUSED_SLOTS")) {   // tuning aid: force 16 or 32
             const int v = atoi(fs);
             if (v == 16 || v == 32) e->fused_slots = v;
@@ -2121,7 +2338,12 @@ int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *prior
         const dim3 g32((e->d.G + 31) / 32), g16((e->d.G + 15) / 16), blk(c4net::NTHREADS);
 #define C4_LAUNCH_WAVE(MODE)                                                                                                       \
     do {                                                                                                                           \
-        if (e->fused_slots == 32) hipLaunchKernelGGL((c4_selfplay_wave_kernel<32, MODE>), g32, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps); \
+        if (e->fused_wave == 2) {                                                                                                  \
+            if (e->fused_slots != 32 && e->split_tw == 5) hipLaunchKernelGGL((c4_selfplay_split_kernel<16, MODE, 5>), g16, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps); \
+            else if (e->fused_slots != 32 && e->split_tw == 6) hipLaunchKernelGGL((c4_selfplay_split_kernel<16, MODE, 6>), g16, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps); \
+            else if (e->fused_slots == 32) hipLaunchKernelGGL((c4_selfplay_split_kernel<32, MODE>), g32, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps); \
+            else hipLaunchKernelGGL((c4_selfplay_split_kernel<16, MODE>), g16, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps); \
+        } else if (e->fused_slots == 32) hipLaunchKernelGGL((c4_selfplay_wave_kernel<32, MODE>), g32, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps); \
         else hipLaunchKernelGGL((c4_selfplay_wave_kernel<16, MODE>), g16, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps); \
     } while (0)
         if (nd.mode == c4net::NETMODE_F64) C4_LAUNCH_WAVE(c4net::NETMODE_F64);

@@ -135,7 +135,7 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
     const int FW = desc->filters;
     if ((FW != 32 && FW != 64) || desc->channels != 3 || desc->n_residuals < 0 ||
         FW * (1 + 2 * desc->n_residuals) > BIAS_LDS_FLOATS) {
-        snprintf(n_err, 512, "fused net supports channels=3, filters 32 (<= 64 residual blocks) or 64 (<= 32) "
+        snprintf(n_err, 512, "fused net supports channels=3, filters 32 (<= 16 residual blocks) or 64 (<= 7) "
                  "(got channels=%d filters=%d residuals=%d)", desc->channels, desc->filters, desc->n_residuals);
         return C4_EINVAL;
     }

@@ -110,12 +110,13 @@ class FusedNet:
 def make_selfplay_net(state_dict, device: int = 0, precision: str = "f16"):
     """The fastest evaluator this build has for a checkpoint: the fused MFMA forwards for 32 filters (the
     reference's default, config.py:8-12; fp16 or reference precision) and for 64 filters (its example_config,
-    data/example_config.py:8-16; fp16), any number of residual blocks / value-head Linear layers; anything
-    else runs through the PyTorch-ROCm plan (connect4_amd.net.InferenceNet, fp32).  All plug into SelfPlay /
+    data/example_config.py:8-16; fp16), up to 16 / 7 residual blocks (their biases live in LDS) and any number
+    of value-head Linear layers; anything else runs through the PyTorch-ROCm plan (connect4_amd.net.InferenceNet, fp32).  All plug into SelfPlay /
     generate_games / DeviceNetEvaluator unchanged."""
     import torch
     cfg = PolicyValueNet.config_from_state_dict(state_dict)
-    if cfg.channels == 3 and (cfg.filters == 32 or (cfg.filters == 64 and precision == "f16")):
+    fits = (cfg.filters == 32 and cfg.n_residuals <= 16) or (cfg.filters == 64 and cfg.n_residuals <= 7 and precision == "f16")
+    if cfg.channels == 3 and fits:
         return FusedNet(state_dict, device=device, precision=precision)
     from .net import InferenceNet
     return InferenceNet(state_dict, device="cuda:%d" % device, dtype=torch.float32)

@@ -292,7 +292,7 @@ int c4_board_centre_value(int device, const uint64_t *color0, const uint64_t *co
  *   pfc_w [7][84], pfc_b [7]                   policy_head.fc1 (model.py:104,113)
  *   w1, w2                                     value_head.w1/w2 (model.py:74-75,88) */
 /* arithmetic of the fused forwards */
-#define C4_NET_F16 0    /* fp16 storage, fp32 accumulation: one v_mfma_f32_32x32x16_f16 per k-step */
+#define C4_NET_F16 0    /* fp16 storage, fp32 accumulation: one MFMA per k-step */
 #define C4_NET_F32X3 1  /* reference precision: fp32 operands split into fp16 hi + scaled lo, three MFMAs per k-step */
 typedef struct {
     int32_t channels, filters, n_residuals;

@@ -178,9 +178,9 @@ def test_fused_selfplay_kernel_equals_separate_kernels(monkeypatch):
     net = FusedNet(random_init_state_dict(seed=0))
     cfg = MCTSConfig.self_play(48)
     out = []
-    # separate kernels; then the wave-autonomous and the workgroup-synchronous fused kernel, each with 16 and
-    # 32 slots per workgroup (72 slots: ragged last workgroup)
-    for mode, fused in (("wave", 0), ("wave", 16), ("wave", 32), ("block", 16), ("block", 32)):
+    # separate kernels; then the three fused kernels (tree waves + network waves, wave-autonomous, workgroup-synchronous),
+    # each with 16 and 32 slots per workgroup (72 slots: ragged last workgroup)
+    for mode, fused in (("wave", 0), ("split", 16), ("split", 32), ("wave", 16), ("wave", 32), ("block", 16), ("block", 32)):
         monkeypatch.setenv("C4_FUSED_MODE", mode)
         monkeypatch.setenv("C4_FUSED_SLOTS", str(fused or 16))
         sp = SelfPlay(net, 72, cfg, seed=11, games_target=96, record_capacity_games=96, use_graph=False,

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Diagnostic: busy cycles of the tree waves and network waves of c4_selfplay_split_kernel (C4_TREE_STAMPS=1)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+os.environ["C4_TREE_STAMPS"] = "1"
+os.environ["C4_FUSED_MODE"] = "split"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from connect4_amd.config import MCTSConfig  # noqa: E402
+from connect4_amd.fused_net import FusedNet  # noqa: E402
+from connect4_amd.net import random_init_state_dict  # noqa: E402
+from connect4_amd.selfplay import SelfPlay  # noqa: E402
+
+slots = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+tw = int(os.environ.get("C4_SPLIT_TW", "4"))
+net = FusedNet(random_init_state_dict(seed=0))
+sp = SelfPlay(net, slots, MCTSConfig.self_play(800), seed=0, use_graph=False, fused_loop=True, steps_per_launch=64, max_inner_iters=32)
+sp.run_steps(6400)
+sp.synchronize()
+s0 = sp.stats()
+sp.run_steps(64)
+sp.synchronize()
+s1 = sp.stats()
+out = (C.c_uint64 * 2048)()
+assert sp.engine._lib.c4_debug_stamps(sp.engine._h, out) == 0
+a = np.array(list(out), dtype=np.uint64).reshape(128, 16)
+nw = 8 - tw
+mask = np.uint64((1 << 48) - 1)
+tree = (a[:, 0:tw] & mask).astype(np.float64) / 64
+netb = (a[:, 8:8 + nw] & mask).astype(np.float64) / 64
+npass = (a[:, 8:8 + nw] >> np.uint64(48)).astype(np.float64) / 64
+print("slots %d  tree waves %d: busy cycles per 80k-cycle step: mean %.0f p5 %.0f p95 %.0f" % (slots, tw, tree.mean(), np.percentile(tree, 5), np.percentile(tree, 95)))
+print("network waves %d: busy %.0f cycles per step (p95 %.0f), %.2f passes per step -> %.0f cycles per pass" %
+      (nw, netb.mean(), np.percentile(netb, 95), npass.mean(), netb.sum() / max(1.0, npass.sum())))
+if tw == 4:
+    fl = a[:, 4:8]
+    print("placement: two waves per SIMD in %d of %d workgroups; SIMD ids of tree waves 0..3 of workgroup 0: %s" %
+          (int(((fl >> np.uint64(8)) & np.uint64(1)).all(axis=1).sum()), len(fl), (fl[0] & np.uint64(3)).tolist()))
+print("simulations per slot and step: %.2f" % ((s1["simulations"] - s0["simulations"]) / 64.0 / slots))

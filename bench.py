@@ -8,7 +8,7 @@ empty board, weights are seeded random-init.
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" = ONE launch of the persistent self-play kernel (c4_selfplay_wave_kernel): `--quanta-per-step`
+A "step" = ONE launch of the persistent self-play kernel (c4_selfplay_split_kernel: tree waves + network waves): `--quanta-per-step`
 (256) time quanta of `--time-budget` (80,000) shader cycles for every one of the 4096 games per GPU,
 about 9 ms, in which every game completes several hundred simulations (tree walk + network on the
 leaves).  K of them are timed exactly, after W untimed ones.
@@ -36,6 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# the fused kernel c4_selfplay_steps launches (C4_FUSED_MODE selects the older variants for A/B runs)
+FUSED_KERNEL = {"wave": "c4_selfplay_wave_kernel", "block": "c4_selfplay_kernel"}.get(os.environ.get("C4_FUSED_MODE", ""), "c4_selfplay_split_kernel")
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 FP32_MATRIX_PEAK_TF = 157.3  # fp32-in MFMA / vector peak
 F16_MFMA_PEAK_TF = 2500.0    # dense
@@ -391,13 +393,13 @@ def run_rank(args):
             ach = tree_b / (launch_ms * 1e-3) / 1e9
             mfma_tf = args.net_mflop * 1e6 * r_evals / (launch_ms * 1e-3) / 1e12
             # PMC traffic only from a record of launches of exactly this shape
-            pmc_ok = (pmc.get("kernel", "") == "c4_selfplay_wave_kernel" and args.slots == pmc.get("slots") and args.sims == pmc.get("sims")
+            pmc_ok = (pmc.get("kernel", "") == FUSED_KERNEL and args.slots == pmc.get("slots") and args.sims == pmc.get("sims")
                       and args.max_inner == pmc.get("max_inner") and args.quanta_per_step == pmc.get("quanta_per_launch")
                       and args.time_budget == pmc.get("time_budget_cycles") and args.net_precision == pmc.get("net_precision", "f16")
                       and args.filters == pmc.get("filters", 32) and args.residuals == pmc.get("residuals", 3)
                       and "FETCH_SIZE_fused" in pmc)
             fused = {
-                "kernel": "c4_selfplay_wave_kernel (per wave: PUCT tree walk of its slots + policy/value net on their leaves; the only kernel of the timed region)",
+                "kernel": FUSED_KERNEL + " (tree waves: PUCT tree walk of their slots; network waves: policy/value net on the posted leaves; the only kernel of the timed region)",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                 "traffic": ((2.0 * pmc["FETCH_SIZE_fused"] + pmc["WRITE_SIZE_fused"]) * 1024.0 if pmc_ok else None),
                 "traffic_source": (os.path.relpath(PMC_FILE, ROOT) if pmc_ok else None),

@@ -50,6 +50,9 @@
 #ifndef C4_ASM_PICK
 #define C4_ASM_PICK 1         // butterfly step written out in assembly (compare, select and DPP moves in one block)
 #endif
+#ifndef C4_SPLIT_PAIRS
+#define C4_SPLIT_PAIRS 1      // split kernel: a network wave takes two waiting requests into one pass (tuning aid: 0 = one position per pass)
+#endif
 #ifndef C4_EARLY_REQUEST
 #define C4_EARLY_REQUEST 1   // software-pipelined level loop (tuning aid: -DC4_EARLY_REQUEST=0 restores the plain loop)
 #endif
@@ -1543,7 +1546,10 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
     constexpr int NW = NWAVES - TW;           // tree waves, network waves (TW = 4: one of each per SIMD)
     constexpr int SPW = (TS + TW - 1) / TW;   // slots per tree wave (at most)
     static_assert(TW >= 1 && NW >= 1 && SPW >= 1 && SPW <= 8 && TS <= 64, "slots per workgroup");
-    constexpr int WBUF = WaveBuf<MODE>::HALVES;
+    // two positions per pass when two requests wait: pays once the network waves are the busier half (32 slots per CU: +1.5 %;
+    // 16 slots: -1.5 %)
+    constexpr bool PAIRS = MODE == NETMODE_F32_F16 && TS == 32 && C4_SPLIT_PAIRS;
+    constexpr int WBUF = WaveBuf<MODE>::HALVES * (PAIRS ? 2 : 1);
     __shared__ __attribute__((aligned(16))) _Float16 act[NW][WBUF];   // planes of the network waves
     __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
     __shared__ SlotMem smem[TS];
@@ -1645,17 +1651,39 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
             }
             // start looking at a different slot on every network wave, so that they do not race for the same request
             const int rot = (nw * TS) / NW;
-            const unsigned long long mr = ((m >> rot) | (m << (TS - rot))) & ((TS == 64) ? ~0ull : ((1ull << TS) - 1));
-            int c = (__builtin_ctzll(mr) + rot) % TS;
-            c = __builtin_amdgcn_readfirstlane(c);
-            int ok = 0;
-            if (lw == 0) ok = atomicCAS(&s_req[c], REQ_POSTED, REQ_TAKEN) == REQ_POSTED;
-            ok = __builtin_amdgcn_readfirstlane(ok);
-            if (!ok) continue;
+            constexpr unsigned long long ALL = (TS == 64) ? ~0ull : ((1ull << TS) - 1);
+            auto first_from = [&](unsigned long long mm) -> int {
+                const unsigned long long mr = ((mm >> rot) | (mm << (TS - rot))) & ALL;
+                return __builtin_amdgcn_readfirstlane((__builtin_ctzll(mr) + rot) % TS);
+            };
+            auto claim = [&](int slot) -> int {
+                int ok = 0;
+                if (lw == 0) ok = atomicCAS(&s_req[slot], REQ_POSTED, REQ_TAKEN) == REQ_POSTED;
+                return __builtin_amdgcn_readfirstlane(ok);
+            };
+            const int c = first_from(m);
+            if (!claim(c)) continue;
             const unsigned long long ta = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
-            net_forward_wave1_mode<MODE>(nd, &act[nw][0], mlp, s_bias, s_tab16, smem[c].leaf0, smem[c].leaf1, s_val, s_pri, c);
+            m &= ~(1ull << c);
+            int c2 = -1;
+            if (PAIRS && m != 0) {   // a second request is waiting: both in one pass (12 independent accumulator tiles keep the MFMA pipe busier)
+                c2 = first_from(m);
+                if (!claim(c2)) c2 = -1;
+            }
+            if (PAIRS && c2 >= 0) {
+                const uint64_t a0[2] = {smem[c].leaf0, smem[c2].leaf0}, a1[2] = {smem[c].leaf1, smem[c2].leaf1};
+                const int o[2] = {c, c2};
+                net_forward_wave16n<2>(nd, &act[nw][0], mlp, s_bias, s_tab16, a0, a1, s_val, s_pri, o);
+            } else {
+                net_forward_wave1_mode<MODE>(nd, &act[nw][0], mlp, s_bias, s_tab16, smem[c].leaf0, smem[c].leaf1, s_val, s_pri, c,
+                                             (C4_FUSED_NET_STAMPS && d.has_stamps && blockIdx.x < 16) ? d.cold->stamps + 2048 + (blockIdx.x * NWAVES + nw) * 16 : nullptr);
+            }
             lds_fence();   // the answer is in LDS before the request word says so
-            if (lw == 0) *(volatile uint32_t *)&s_req[c] = REQ_ANSWERED;
+            if (lw == 0) {
+                *(volatile uint32_t *)&s_req[c] = REQ_ANSWERED;
+                if (PAIRS && c2 >= 0) *(volatile uint32_t *)&s_req[c2] = REQ_ANSWERED;
+            }
+            if (PAIRS && c2 >= 0) n_pass += 1;
             if (d.has_stamps) { t_busy += __builtin_amdgcn_s_memtime() - ta; n_pass += 1; }
         }
     }
@@ -1971,7 +1999,7 @@ struct c4_engine {
     int64_t launches;
     int fused_slots;      // slots per workgroup of the fused self-play kernel (16 or 32)
     int fused_wave;       // 1: wave-autonomous fused kernel (c4_selfplay_wave_kernel); 2: tree waves + network waves (c4_selfplay_split_kernel)
-    int split_tw;         // tuning aid (C4_SPLIT_TW): tree waves of the split kernel at 16 slots per workgroup
+    int split_tw;         // tuning aid (C4_SPLIT_TW=2|4): tree waves of the split kernel at 16 slots per workgroup; 0 = by net mode
     int tape_games;
     double *tape_noise, *tape_u;
     char err[512];
@@ -2095,9 +2123,9 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
         e->fused_slots = ((cfg->n_slots + 31) / 32 >= cus) ? 32 : 16;
-        e->fused_wave = 1;   // wave-autonomous kernel; C4_FUSED_MODE=block selects the workgroup-synchronous one
-        if (const char *fm = getenv("C4_FUSED_MODE")) e->fused_wave = strcmp(fm, "block") == 0 ? 0 : (strcmp(fm, "split") == 0 ? 2 : 1);
-        e->split_tw = 4;
+        e->fused_wave = 2;   // tree waves + network waves; C4_FUSED_MODE=wave / block select the wave-autonomous / workgroup-synchronous kernels
+        if (const char *fm = getenv("C4_FUSED_MODE")) e->fused_wave = strcmp(fm, "block") == 0 ? 0 : (strcmp(fm, "wave") == 0 ? 1 : 2);
+        e->split_tw = 0;     // 0: chosen by the net's mode
         if (const char *tw = getenv("C4_SPLIT_TW")) e->split_tw = atoi(tw);
         if (const char *fs = getenv("C4_FUSED_SLOTS")) {   // tuning aid: force 16 or 32
             const int v = atoi(fs);
@@ -2336,13 +2364,17 @@ int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *prior
             e->d_uploaded = e->d;
         }
         const dim3 g32((e->d.G + 31) / 32), g16((e->d.G + 15) / 16), blk(c4net::NTHREADS);
+        // tree waves of the split kernel: 4 (one per SIMD) for the 32-filter fp16 net; the slower forwards (reference precision,
+        // 64 filters) need more network waves: 2 tree waves of 8 slots and 6 network waves at 16 slots per CU (measured:
+        // f32x3 203 vs 184 M expansions/s, 64 filters 72 vs 62 M)
+        const int tw = e->split_tw ? e->split_tw : (nd.mode == c4net::NETMODE_F32_F16 ? 4 : 2);
+#define C4_LAUNCH_SPLIT(TSV, MODE, TWV) hipLaunchKernelGGL((c4_selfplay_split_kernel<TSV, MODE, TWV>), (TSV == 32 ? g32 : g16), blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps)
 #define C4_LAUNCH_WAVE(MODE)                                                                                                       \
     do {                                                                                                                           \
         if (e->fused_wave == 2) {                                                                                                  \
-            if (e->fused_slots != 32 && e->split_tw == 5) hipLaunchKernelGGL((c4_selfplay_split_kernel<16, MODE, 5>), g16, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps); \
-            else if (e->fused_slots != 32 && e->split_tw == 6) hipLaunchKernelGGL((c4_selfplay_split_kernel<16, MODE, 6>), g16, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps); \
-            else if (e->fused_slots == 32) hipLaunchKernelGGL((c4_selfplay_split_kernel<32, MODE>), g32, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps); \
-            else hipLaunchKernelGGL((c4_selfplay_split_kernel<16, MODE>), g16, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps); \
+            if (e->fused_slots == 32) C4_LAUNCH_SPLIT(32, MODE, 4);                                                                \
+            else if (tw == 2) C4_LAUNCH_SPLIT(16, MODE, 2);                                                                        \
+            else C4_LAUNCH_SPLIT(16, MODE, 4);                                                                                     \
         } else if (e->fused_slots == 32) hipLaunchKernelGGL((c4_selfplay_wave_kernel<32, MODE>), g32, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps); \
         else hipLaunchKernelGGL((c4_selfplay_wave_kernel<16, MODE>), g16, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps); \
     } while (0)
@@ -2350,6 +2382,7 @@ int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *prior
         else if (nd.mode == c4net::NETMODE_F32_PRECISE) C4_LAUNCH_WAVE(c4net::NETMODE_F32_PRECISE);
         else C4_LAUNCH_WAVE(c4net::NETMODE_F32_F16);
 #undef C4_LAUNCH_WAVE
+#undef C4_LAUNCH_SPLIT
     } else if (nd.mode != c4net::NETMODE_F32_F16) {
         set_err(e->err, "C4_FUSED_MODE=block serves only the 32-filter fp16 net; use the default wave-autonomous kernel");
         return C4_ESTATE;

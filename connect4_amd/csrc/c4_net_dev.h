@@ -794,9 +794,11 @@ __device__ __forceinline__ void store16(const floatx4 &acc, _Float16 *dst, int o
     if (real) *reinterpret_cast<half4 *>(dst + off) = o;
 }
 
-__device__ __forceinline__ void net_forward_wave16(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds,
-                                                   const uint16_t *tab, uint64_t b0, uint64_t b1, float *__restrict__ values,
-                                                   float *__restrict__ priors, int out, unsigned long long *stamps = nullptr)
+template <int NP>
+__device__ __forceinline__ void net_forward_wave16n(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds,
+                                                    const uint16_t *tab, const uint64_t (&b0)[NP], const uint64_t (&b1)[NP],
+                                                    float *__restrict__ values, float *__restrict__ priors, const int (&out)[NP],
+                                                    unsigned long long *stamps = nullptr)
 {
     int lane_ = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_));     // inside a persistent kernel the compiler would otherwise hoist every lane-derived address of this function out of the caller's step loop, keep them live across the tree walk and reload them from scratch mid-pass
@@ -805,7 +807,9 @@ __device__ __forceinline__ void net_forward_wave16(const NetDev &nd, _Float16 *b
     auto stamp = [&](int i) { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); };
     stamp(0);
     const int n_layers = 2 * nd.n_res;
-    _Float16 *const p0 = buf, *const p1 = buf + PLANE16;
+    // position i: ping plane at buf + 2 i PLANE16, pong plane behind it
+#define P0(i) (buf + (2 * (i)) * PLANE16)
+#define P1(i) (buf + (2 * (i) + 1) * PLANE16)
     // weights: the layer's 18 fragments (tap t, cout tile ct) at [(L*9 + t)*2 + ct][64 lanes], a layer ahead
     half8 w[18];
     if (n_layers > 0) {
@@ -823,20 +827,23 @@ __device__ __forceinline__ void net_forward_wave16(const NetDev &nd, _Float16 *b
         for (int i = 0; i < TAB16 / 8; ++i) { const uint4 v = t4[i]; tb[4 * i] = v.x; tb[4 * i + 1] = v.y; tb[4 * i + 2] = v.z; tb[4 * i + 3] = v.w; }
     }
     auto tof = [&](int idx) -> int { return (int)((tb[idx >> 1] >> (16 * (idx & 1))) & 0xffffu); };
-    // input planes (board.py:147-154), 4 halves per row, at the start of p1 (the tower writes p1 only after the stem)
-    _Float16 *inp = p1;
-    if (lane <= PIX) {
-        half4 v = {};
-        if (lane < PIX) {
-            const int y = lane / 7, x = lane - y * 7;
-            const int bit = x * 7 + (5 - y);
-            v[0] = (_Float16)((__popcll(b0 | b1) & 1) ? 0.0f : 1.0f);
-            v[1] = (_Float16)(float)((b0 >> bit) & 1);
-            v[2] = (_Float16)(float)((b1 >> bit) & 1);
+    // input planes (board.py:147-154), 4 halves per row, at the start of the pong plane (the tower writes it only after the stem)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        _Float16 *inp = P1(i);
+        if (lane <= PIX) {
+            half4 v = {};
+            if (lane < PIX) {
+                const int y = lane / 7, x = lane - y * 7;
+                const int bit = x * 7 + (5 - y);
+                v[0] = (_Float16)((__popcll(b0[i] | b1[i]) & 1) ? 0.0f : 1.0f);
+                v[1] = (_Float16)(float)((b0[i] >> bit) & 1);
+                v[2] = (_Float16)(float)((b1[i] >> bit) & 1);
+            }
+            *reinterpret_cast<half4 *>(inp + lane * 4) = v;   // lane == PIX: the zero row of the planes
         }
-        *reinterpret_cast<half4 *>(inp + lane * 4) = v;   // lane == PIX: the zero row of the planes
+        if (lane < CS16) { P0(i)[PIX * CS16 + lane] = (_Float16)0.0f; P1(i)[PIX * CS16 + lane] = (_Float16)0.0f; }
     }
-    if (lane < CS16) { p0[PIX * CS16 + lane] = (_Float16)0.0f; p1[PIX * CS16 + lane] = (_Float16)0.0f; }
     bool real[RT16];
     int rbase[RT16];
 #pragma unroll
@@ -851,96 +858,117 @@ __device__ __forceinline__ void net_forward_wave16(const NetDev &nd, _Float16 *b
     };
     // ------------------------------------------------------------------ stem: planes -> p0   (K = 36 -> two k-steps of 32)
     {
-        floatx4 acc[RT16][2];
+        floatx4 acc[NP][RT16][2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const floatx4 bv = bias4(bias_lds, ct);
 #pragma unroll
-            for (int rt = 0; rt < RT16; ++rt) acc[rt][ct] = bv;
+            for (int i = 0; i < NP; ++i)
+#pragma unroll
+                for (int rt = 0; rt < RT16; ++rt) acc[i][rt][ct] = bv;
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int rt = 0; rt < RT16; ++rt) {
-                const half4 va = *reinterpret_cast<const half4 *>(inp + tof(27 + rt * 4 + s * 2));
-                const half4 vb = *reinterpret_cast<const half4 *>(inp + tof(27 + rt * 4 + s * 2 + 1));
-                half8 bf;
+            for (int i = 0; i < NP; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { bf[j] = va[j]; bf[4 + j] = vb[j]; }
+                for (int rt = 0; rt < RT16; ++rt) {
+                    const half4 va = *reinterpret_cast<const half4 *>(P1(i) + tof(27 + rt * 4 + s * 2));
+                    const half4 vb = *reinterpret_cast<const half4 *>(P1(i) + tof(27 + rt * 4 + s * 2 + 1));
+                    half8 bf;
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sw[s * 2 + ct], bf, acc[rt][ct], 0, 0, 0);
-            }
+                    for (int j = 0; j < 4; ++j) { bf[j] = va[j]; bf[4 + j] = vb[j]; }
 #pragma unroll
-        for (int rt = 0; rt < RT16; ++rt)
+                    for (int ct = 0; ct < 2; ++ct) acc[i][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sw[s * 2 + ct], bf, acc[i][rt][ct], 0, 0, 0);
+                }
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) store16(acc[rt][ct], p0, rbase[rt] + 16 * ct + 4 * g, real[rt]);
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) store16(acc[i][rt][ct], P0(i), rbase[rt] + 16 * ct + 4 * g, real[rt]);
     }
     stamp(1);
     // ------------------------------------------------------------------ residual tower
     for (int L = 0; L < n_layers; ++L) {
         const bool second = L & 1;
-        const _Float16 *src = second ? p1 : p0;
-        _Float16 *dst = second ? p0 : p1;
-        floatx4 acc[RT16][2];
+        const int so = second ? PLANE16 : 0, dofs = second ? 0 : PLANE16;   // source / destination plane inside a position's pair
+        floatx4 acc[NP][RT16][2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const floatx4 bv = bias4(bias_lds + F * (1 + L), ct);
 #pragma unroll
-            for (int rt = 0; rt < RT16; ++rt) acc[rt][ct] = bv;
+            for (int i = 0; i < NP; ++i)
+#pragma unroll
+                for (int rt = 0; rt < RT16; ++rt) acc[i][rt][ct] = bv;
         }
         const int Ln = L + 1 < n_layers ? L + 1 : 0;       // unconditional refill: a branch around the loads makes the compiler drain vmcnt in front of each
         const half8 *wnext = nd.conv_w16 + (size_t)Ln * 18 * 64 + lane;
-        half8 bc[RT16], bn[RT16];
+        half8 bc[NP][RT16], bn[NP][RT16];
 #pragma unroll
-        for (int rt = 0; rt < RT16; ++rt) bc[rt] = *reinterpret_cast<const half8 *>(src + tof(rt * 9));
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) bc[i][rt] = *reinterpret_cast<const half8 *>(P0(i) + so + tof(rt * 9));
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             if (t + 1 < 9) {
 #pragma unroll
-                for (int rt = 0; rt < RT16; ++rt) bn[rt] = *reinterpret_cast<const half8 *>(src + tof(rt * 9 + t + 1));
+                for (int i = 0; i < NP; ++i)
+#pragma unroll
+                    for (int rt = 0; rt < RT16; ++rt) bn[i][rt] = *reinterpret_cast<const half8 *>(P0(i) + so + tof(rt * 9 + t + 1));
             }
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
-                for (int rt = 0; rt < RT16; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[2 * t + ct], bc[rt], acc[rt][ct], 0, 0, 0);
+                for (int i = 0; i < NP; ++i)
+#pragma unroll
+                    for (int rt = 0; rt < RT16; ++rt) acc[i][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[2 * t + ct], bc[i][rt], acc[i][rt][ct], 0, 0, 0);
                 w[2 * t + ct] = wnext[(2 * t + ct) * 64];
             }
 #pragma unroll
-            for (int rt = 0; rt < RT16; ++rt) bc[rt] = bn[rt];
+            for (int i = 0; i < NP; ++i)
+#pragma unroll
+                for (int rt = 0; rt < RT16; ++rt) bc[i][rt] = bn[i][rt];
         }
         if (L == 2) stamp(12);
         if (second) {   // + block input (lives in dst): skip[cout][pixel] = sum_k I[cout][k] x[k][pixel]
 #pragma unroll
-            for (int rt = 0; rt < RT16; ++rt) {
-                const half8 x = *reinterpret_cast<const half8 *>(dst + rbase[rt] + 8 * g);
+            for (int i = 0; i < NP; ++i)
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    half8 idf;      // identity fragment of cout tile ct: A[cout n][cin 8g + j] = (8g + j == 16 ct + n)
+                for (int rt = 0; rt < RT16; ++rt) {
+                    const half8 x = *reinterpret_cast<const half8 *>(P0(i) + dofs + rbase[rt] + 8 * g);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) idf[j] = (_Float16)((8 * g + j) == 16 * ct + n ? 1.0f : 0.0f);
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(idf, x, acc[rt][ct], 0, 0, 0);
+                    for (int ct = 0; ct < 2; ++ct) {
+                        half8 idf;      // identity fragment of cout tile ct: A[cout n][cin 8g + j] = (8g + j == 16 ct + n)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) idf[j] = (_Float16)((8 * g + j) == 16 * ct + n ? 1.0f : 0.0f);
+                        acc[i][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(idf, x, acc[i][rt][ct], 0, 0, 0);
+                    }
                 }
-            }
         }
         if (L == 2) stamp(13);
 #pragma unroll
-        for (int rt = 0; rt < RT16; ++rt)
+        for (int i = 0; i < NP; ++i)
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) store16(acc[rt][ct], dst, rbase[rt] + 16 * ct + 4 * g, real[rt]);
+            for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) store16(acc[i][rt][ct], P0(i) + dofs, rbase[rt] + 16 * ct + 4 * g, real[rt]);
         if (L == 2) stamp(14);
         if (L < 6) stamp(2 + L);
     }
     stamp(8);
     // tower output is in p0 (n_layers is even)
     // ------------------------------------------------------------------ 1x1 head convs: couts 0..2 = rows 0..2 of cout tile 0
-    float *hs = reinterpret_cast<float *>(p1);   // [HSTR] fp32: value plane 0..41, policy planes 42..125 (p1 is free)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+    float *hs = reinterpret_cast<float *>(P1(i));   // [HSTR] fp32: value plane 0..41, policy planes 42..125 (the pong plane is free)
     {
         const half8 hw = nd.head_w16[lane];
         const float hb0 = nd.head_b[0], hb1 = nd.head_b[1], hb2 = nd.head_b[2];
         floatx4 a[RT16];
 #pragma unroll
         for (int rt = 0; rt < RT16; ++rt) {
-            const half8 x = *reinterpret_cast<const half8 *>(p0 + rbase[rt] + 8 * g);
+            const half8 x = *reinterpret_cast<const half8 *>(P0(i) + rbase[rt] + 8 * g);
             a[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hw, x, floatx4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
         }
 #pragma unroll
@@ -954,7 +982,7 @@ __device__ __forceinline__ void net_forward_wave16(const NetDev &nd, _Float16 *b
         }
         if (lane < 2) hs[HEADV + lane] = 0.0f;   // pad 126,127
     }
-    stamp(9);
+    if (i == NP - 1) stamp(9);
     // ------------------------------------------------------------------ MLP heads (fp32 VALU), as in net_forward_block
     {
         const float *vt_b = reinterpret_cast<const float *>(mlp + VT_F4 + PT_F / 4);   // fc_b | vout_w | pfc_b
@@ -989,10 +1017,23 @@ __device__ __forceinline__ void net_forward_wave16(const NetDev &nd, _Float16 *b
         const float mx = max8(is_pol ? lg : -INFINITY);
         const float e = is_pol ? expf(lg - mx) : 0.0f;
         const float sum = sum8(e);
-        if (lane == 0) values[out] = value;
-        if (is_pol) priors[(size_t)out * 7 + lane] = e / sum;
+        if (lane == 0) values[out[i]] = value;
+        if (is_pol) priors[(size_t)out[i] * 7 + lane] = e / sum;
+    }
     }
     stamp(10);
+#undef P0
+#undef P1
+}
+
+// one position per pass (the form the standalone kernel and the wave-autonomous self-play kernel use)
+__device__ __forceinline__ void net_forward_wave16(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds,
+                                                   const uint16_t *tab, uint64_t b0, uint64_t b1, float *__restrict__ values,
+                                                   float *__restrict__ priors, int out, unsigned long long *stamps = nullptr)
+{
+    const uint64_t a0[1] = {b0}, a1[1] = {b1};
+    const int o[1] = {out};
+    net_forward_wave16n<1>(nd, buf, mlp, bias_lds, tab, a0, a1, values, priors, o, stamps);
 }
 
 // ------------------------------------------------------------------------------------------------

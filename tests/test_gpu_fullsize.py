@@ -1,6 +1,6 @@
 """BASELINE shapes at FULL size under -m gpu.
 
-(i)  configs[1]: 4096 games x 800 simulations on the PRODUCTION path -- c4_selfplay_wave_kernel + the 2^28-entry
+(i)  configs[1]: 4096 games x 800 simulations on the PRODUCTION path -- c4_selfplay_split_kernel + the 2^28-entry
      evaluation cache + the fused MFMA net -- with injected RNG tapes, then a sample of the finished games is
      replayed move for move on the CPU oracle, whose evaluator answers with what the device's evaluation cache
      holds for each position (c4_eval_cache_lookup; FusedNet for a position the direct-mapped table has since

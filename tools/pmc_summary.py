@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel means of the rocprofv3 --pmc passes written by tools/pmc_passes.sh.
 
-    python tools/pmc_summary.py gpurun_out/pmc_r2 [--kernel c4_selfplay_wave_kernel] [--json out.json]
+    python tools/pmc_summary.py gpurun_out/pmc_r2 [--kernel c4_selfplay_split_kernel] [--json out.json]
 
 For every counter: the mean per launch over the second half of the kernel's dispatches (steady state)."""
 import argparse
@@ -15,7 +15,7 @@ import sys
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("out_dir")
-    ap.add_argument("--kernel", default="c4_selfplay_wave_kernel")
+    ap.add_argument("--kernel", default="c4_selfplay_split_kernel")
     ap.add_argument("--json", default=None)
     a = ap.parse_args()
     res = {}

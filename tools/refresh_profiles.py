@@ -11,7 +11,7 @@ P = os.path.join(R, "profiles")
 s = json.load(open(os.path.join(O, "pmc", "summary.json")))
 b = json.load(open(os.path.join(O, "bench_final.json")))
 cfg = b["config"]
-json.dump({"kernel": "c4_selfplay_wave_kernel", "slots": cfg["slots_per_gpu"], "sims": cfg["simulations"], "filters": 32, "residuals": 3,
+json.dump({"kernel": "c4_selfplay_split_kernel", "slots": cfg["slots_per_gpu"], "sims": cfg["simulations"], "filters": 32, "residuals": 3,
            "max_inner": cfg["max_inner_iters"], "quanta_per_launch": cfg["quanta_per_step"], "time_budget_cycles": cfg["time_budget_cycles"],
            "net_precision": "f16",
            "note": "KB per launch as reported by rocprofv3 --pmc (separate FETCH_SIZE and WRITE_SIZE passes, tools/pmc_passes.sh: `rocprofv3 --kernel-trace "
@@ -22,8 +22,8 @@ json.dump({"kernel": "c4_selfplay_wave_kernel", "slots": cfg["slots_per_gpu"], "
            "launches_averaged": s["FETCH_SIZE"]["launches_averaged"]}, open(os.path.join(P, "r02_pmc_traffic.json"), "w"), indent=1)
 sq = {k: v["mean_per_launch"] for k, v in s.items() if k.startswith("SQ_")}
 wc = sq["SQ_WAVE_CYCLES"]
-json.dump({"kernel": "c4_selfplay_wave_kernel<16, f16>",
-           "per_launch": "256 quanta x 80,000 shader cycles x 2048 waves (4096 games); SQ_WAVE_CYCLES/SQ_WAIT_*/SQ_ACTIVE_INST_* count quad-cycles",
+json.dump({"kernel": "c4_selfplay_split_kernel<16, f16, 4>",
+           "per_launch": "256 quanta x 80,000 shader cycles x 2048 waves (4096 games: 1024 tree waves of 4 slots, 1024 network waves); SQ_WAVE_CYCLES/SQ_WAIT_*/SQ_ACTIVE_INST_* count quad-cycles",
            "command": "bash tools/pmc_passes.sh <dir> (three SQ passes of 8 counters each); python tools/pmc_summary.py <dir>",
            "counters": sq,
            "derived": {"wave_time_waiting_on_waitcnt (SQ_WAIT_ANY / SQ_WAVE_CYCLES)": sq["SQ_WAIT_ANY"] / wc,

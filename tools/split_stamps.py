@@ -40,3 +40,16 @@ if tw == 4:
     print("placement: two waves per SIMD in %d of %d workgroups; SIMD ids of tree waves 0..3 of workgroup 0: %s" %
           (int(((fl >> np.uint64(8)) & np.uint64(1)).all(axis=1).sum()), len(fl), (fl[0] & np.uint64(3)).tolist()))
 print("simulations per slot and step: %.2f" % ((s1["simulations"] - s0["simulations"]) / 64.0 / slots))
+# phases of the last network pass of each network wave of workgroups 0..15, measured inside the split kernel: needs a
+# diagnostic build of the library (hipcc ... -DC4_FUSED_NET_STAMPS=1 -o x.so; C4_ENGINE_LIB=x.so)
+out2 = (C.c_uint64 * 2048)()
+assert sp.engine._lib.c4_debug_fused_net_stamps(sp.engine._h, out2) == 0
+st = np.array(list(out2), dtype=np.int64).reshape(128, 16)
+st = st[st[:, 0] > 0]
+if len(st):
+    names = ["stem"] + ["L%d" % i for i in range(6)] + ["tower_end", "heads", "mlp"]
+    dd = st[:, 1:11] - st[:, 0:10]
+    print("network pass inside the split kernel (%d waves sampled), cycles per phase (median): " % len(st) +
+          " ".join("%s=%d" % (n, x) for n, x in zip(names, np.median(dd, axis=0))) + "  total=%d" % np.median(st[:, 10] - st[:, 0]))
+    print("   layer 2 split (median): k-loop=%d skip=%d epilogue=%d" %
+          (np.median(st[:, 12] - st[:, 3]), np.median(st[:, 13] - st[:, 12]), np.median(st[:, 14] - st[:, 13])))

@@ -794,6 +794,9 @@ __device__ __forceinline__ void store16(const floatx4 &acc, _Float16 *dst, int o
     if (real) *reinterpret_cast<half4 *>(dst + off) = o;
 }
 
+#ifndef C4_NET_BDEPTH
+#define C4_NET_BDEPTH 2   // operand ring of the tower's k-loop: reads run this many taps minus one ahead (3 and 4 measured the same)
+#endif
 template <int NP>
 __device__ __forceinline__ void net_forward_wave16n(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds,
                                                     const uint16_t *tab, const uint64_t (&b0)[NP], const uint64_t (&b1)[NP],
@@ -807,6 +810,7 @@ __device__ __forceinline__ void net_forward_wave16n(const NetDev &nd, _Float16 *
     auto stamp = [&](int i) { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); };
     stamp(0);
     const int n_layers = 2 * nd.n_res;
+    constexpr int BDEPTH = NP == 1 ? C4_NET_BDEPTH : 2;   // ring of operand fragments
     // position i: ping plane at buf + 2 i PLANE16, pong plane behind it
 #define P0(i) (buf + (2 * (i)) * PLANE16)
 #define P1(i) (buf + (2 * (i) + 1) * PLANE16)
@@ -904,31 +908,32 @@ __device__ __forceinline__ void net_forward_wave16n(const NetDev &nd, _Float16 *
         }
         const int Ln = L + 1 < n_layers ? L + 1 : 0;       // unconditional refill: a branch around the loads makes the compiler drain vmcnt in front of each
         const half8 *wnext = nd.conv_w16 + (size_t)Ln * 18 * 64 + lane;
-        half8 bc[NP][RT16], bn[NP][RT16];
+        // operand fragments of tap t sit in ring slot t % BDEPTH; the reads run BDEPTH - 1 taps ahead of the MFMAs
+        half8 bf[BDEPTH][NP][RT16];
 #pragma unroll
-        for (int i = 0; i < NP; ++i)
+        for (int t = 0; t < BDEPTH - 1; ++t)
 #pragma unroll
-            for (int rt = 0; rt < RT16; ++rt) bc[i][rt] = *reinterpret_cast<const half8 *>(P0(i) + so + tof(rt * 9));
+            for (int i = 0; i < NP; ++i)
+#pragma unroll
+                for (int rt = 0; rt < RT16; ++rt) bf[t][i][rt] = *reinterpret_cast<const half8 *>(P0(i) + so + tof(rt * 9 + t));
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            if (t + 1 < 9) {
+            if (t + BDEPTH - 1 < 9) {
 #pragma unroll
                 for (int i = 0; i < NP; ++i)
 #pragma unroll
-                    for (int rt = 0; rt < RT16; ++rt) bn[i][rt] = *reinterpret_cast<const half8 *>(P0(i) + so + tof(rt * 9 + t + 1));
+                    for (int rt = 0; rt < RT16; ++rt)
+                        bf[(t + BDEPTH - 1) % BDEPTH][i][rt] = *reinterpret_cast<const half8 *>(P0(i) + so + tof(rt * 9 + t + BDEPTH - 1));
             }
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
                 for (int i = 0; i < NP; ++i)
 #pragma unroll
-                    for (int rt = 0; rt < RT16; ++rt) acc[i][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[2 * t + ct], bc[i][rt], acc[i][rt][ct], 0, 0, 0);
+                    for (int rt = 0; rt < RT16; ++rt)
+                        acc[i][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[2 * t + ct], bf[t % BDEPTH][i][rt], acc[i][rt][ct], 0, 0, 0);
                 w[2 * t + ct] = wnext[(2 * t + ct) * 64];
             }
-#pragma unroll
-            for (int i = 0; i < NP; ++i)
-#pragma unroll
-                for (int rt = 0; rt < RT16; ++rt) bc[i][rt] = bn[i][rt];
         }
         if (L == 2) stamp(12);
         if (second) {   // + block input (lives in dst): skip[cout][pixel] = sum_k I[cout][k] x[k][pixel]

@@ -380,33 +380,35 @@ struct Pick {      // a candidate child with its record riding along
                  : [m] "s"(m)                                                                             \
                  : "vcc")
 #if C4_ASM_PICK
-// keep-own = (s > os) | (s == os & k >= ok) is computed as wave masks (v_cmp into SGPR pairs + two scalar ops)
-// and goes to VCC once; the own/partner selects of score and index and the v_cndmask_b32_dpp selects of the
-// fields that ride along then all read VCC in one block.  (A ballot of the boolean would be re-materialised
-// by the compiler with a v_cndmask + v_cmp per step.)
+// keep-own = (s > os) | (s == os & own index > partner's index).  In a butterfly over lanes that start with k == lane,
+// the candidates a lane holds at a step all lie on its side of the exchanged bit (step 1: the lane itself; step 2: its
+// pair; step 3: its quad), so "own index > partner's index" is a constant of the lane: the exchanged bit of its lane id.
+// The tie-break therefore needs no index compare and the index itself need not travel through the compares: keep-own =
+// gt | (ge & LANES_WITH_THE_BIT) as wave masks (two v_cmp into SGPR pairs + two scalar ops), to VCC once; the selects of
+// the score and the v_cndmask_b32_dpp selects of the fields that ride along (the index rides in the top bits of n) then
+// all read VCC in one block.
 #define C4_PICK_SELECT(CTRL)                                                                             \
     asm volatile("s_mov_b64 vcc, %[m]\n"                                                                 \
                  "s_nop 0\n"                                                                             \
                  "v_cndmask_b32 %[sl], %[ol], %[sl], vcc\n"                                               \
                  "v_cndmask_b32 %[sh], %[oh], %[sh], vcc\n"                                               \
-                 "v_cndmask_b32 %[k], %[ok], %[k], vcc\n"                                                 \
                  "v_cndmask_b32_dpp %[n], %[n], %[n], vcc " CTRL " row_mask:0xf bank_mask:0xf\n"          \
                  "v_cndmask_b32_dpp %[i], %[i], %[i], vcc " CTRL " row_mask:0xf bank_mask:0xf\n"          \
                  "v_cndmask_b32_dpp %[wl], %[wl], %[wl], vcc " CTRL " row_mask:0xf bank_mask:0xf\n"       \
                  "v_cndmask_b32_dpp %[wh], %[wh], %[wh], vcc " CTRL " row_mask:0xf bank_mask:0xf\n"       \
-                 : [sl] "+v"(sl), [sh] "+v"(sh), [k] "+v"(k), [n] "+v"(n), [i] "+v"(info), [wl] "+v"(wl), [wh] "+v"(wh) \
-                 : [m] "s"(m), [ol] "v"(ol), [oh] "v"(oh), [ok] "v"(ok)                                     \
+                 : [sl] "+v"(sl), [sh] "+v"(sh), [n] "+v"(n), [i] "+v"(info), [wl] "+v"(wl), [wh] "+v"(wh) \
+                 : [m] "s"(m), [ol] "v"(ol), [oh] "v"(oh)                                                   \
                  : "vcc")
 template <int CTRL>
-__device__ __forceinline__ void pick_step(double &s, int &k, uint32_t &n, uint32_t &info, uint32_t &wl, uint32_t &wh)
+__device__ __forceinline__ void pick_step(double &s, uint32_t &n, uint32_t &info, uint32_t &wl, uint32_t &wh)
 {
     const uint64_t sb = (uint64_t)__double_as_longlong(s);
     uint32_t sl = (uint32_t)sb, sh = (uint32_t)(sb >> 32);
     const uint32_t ol = dpp_u32<CTRL>(sl), oh = dpp_u32<CTRL>(sh);
-    const int ok = (int)dpp_u32<CTRL>((uint32_t)k);
     const double os = __longlong_as_double((long long)(((uint64_t)oh << 32) | ol));
-    const unsigned long long m = __builtin_amdgcn_fcmp(s, os, 2 /* ogt */) |
-                                 (__builtin_amdgcn_fcmp(s, os, 1 /* oeq */) & __builtin_amdgcn_sicmp(k, ok, 39 /* sge */));
+    // lanes whose id has the bit this step exchanges: they hold the higher indices
+    constexpr unsigned long long HIGH = CTRL == 0xB1 ? 0xAAAAAAAAAAAAAAAAull : (CTRL == 0x4E ? 0xCCCCCCCCCCCCCCCCull : 0xF0F0F0F0F0F0F0F0ull);
+    const unsigned long long m = __builtin_amdgcn_fcmp(s, os, 2 /* ogt */) | (__builtin_amdgcn_fcmp(s, os, 3 /* oge */) & HIGH);
     if (CTRL == 0xB1) C4_PICK_SELECT("quad_perm:[1,0,3,2]");
     else if (CTRL == 0x4E) C4_PICK_SELECT("quad_perm:[2,3,0,1]");
     else C4_PICK_SELECT("row_half_mirror");
@@ -433,9 +435,19 @@ __device__ __forceinline__ void group_pick(Pick &a)
 {
     const uint64_t wb = (uint64_t)__double_as_longlong(a.w);
     uint32_t wl = (uint32_t)wb, wh = (uint32_t)(wb >> 32);
+#if C4_ASM_PICK
+    // the index rides in the top three bits of the visit count (a search has fewer than 2^19 simulations, c4_engine_create)
+    uint32_t nk = a.n | ((uint32_t)(threadIdx.x & (GROUP - 1)) << 29);
+    pick_step<0xB1>(a.s, nk, a.info, wl, wh);    // quad_perm [1,0,3,2]
+    pick_step<0x4E>(a.s, nk, a.info, wl, wh);    // quad_perm [2,3,0,1]
+    pick_step<0x141>(a.s, nk, a.info, wl, wh);   // row_half_mirror
+    a.k = (int)(nk >> 29);
+    a.n = nk & 0x1fffffffu;
+#else
     pick_step<0xB1>(a.s, a.k, a.n, a.info, wl, wh);    // quad_perm [1,0,3,2]
     pick_step<0x4E>(a.s, a.k, a.n, a.info, wl, wh);    // quad_perm [2,3,0,1]
     pick_step<0x141>(a.s, a.k, a.n, a.info, wl, wh);   // row_half_mirror
+#endif
     a.w = __longlong_as_double((long long)(((uint64_t)wh << 32) | wl));
 }
 

@@ -316,12 +316,14 @@ const char *c4_net_last_error(void);
 
 /* Fused persistent self-play: the rollout step and the leaf evaluation of n_steps steps in ONE launch,
  * no kernel boundary and no global barrier; slot state, leaves and answers stay in LDS for the whole
- * launch.  Default (wave-autonomous kernel): every wave owns 2 slots (4 once n_slots gives every CU a
- * 32-slot workgroup) and alternates the tree walk of its slots with the network on exactly their
- * leaves -- no workgroup barrier either; a "step" is then a time quantum of
- * c4_config.time_budget_cycles shader cycles (80,000 if 0) and the launch runs every wave for n_steps
- * quanta, however many simulations its trees needed per network answer.  With the environment variable
- * C4_FUSED_MODE=block: n_steps rounds of {tree step of the workgroup's 16/32 slots; barrier; network on
+ * launch.  Default (split kernel): on every CU four tree waves own the workgroup's 16 (32) slots and walk their
+ * trees; a slot that needs the evaluator posts its leaf in LDS and idles while its wave's other slots walk on;
+ * four network waves claim posted leaves, run the forward and write the answer back -- no workgroup barrier;
+ * a "step" is a time quantum of c4_config.time_budget_cycles shader cycles (80,000 if 0) and the launch runs
+ * for n_steps quanta, however many simulations the trees needed per network answer.  With the environment
+ * variable C4_FUSED_MODE=wave: every wave owns 2 (4) slots and alternates their tree walk with the network on
+ * exactly their leaves; C4_FUSED_MODE=block: n_steps rounds of {tree step of the workgroup's 16/32 slots;
+ * barrier; network on
  * the emitted leaves, 16 per pass; barrier}.  Either way the games are exactly those that alternating
  * c4_step / c4_net_forward_wave launches play (which launch runs a simulation never changes a result).
  * values_dev float32 [n_slots], priors_dev float32 [n_slots][7] are the hand-off buffers (must persist

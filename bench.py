@@ -315,7 +315,7 @@ def run_rank(args):
     # max elapsed over ranks, sum of units over ranks
     tens = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     keys = ["expansions", "simulations", "games_finished", "moves", "leaf_evals", "terminal_sims", "depth_sum",
-            "children_created", "eval_cache_hits", "eval_cache_probes", "bad_evals"]
+            "children_created", "eval_cache_hits", "eval_cache_probes", "bad_evals", "speculative_evals"]
     units = torch.tensor([delta[k] for k in keys], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tens, op=dist.ReduceOp.MAX)
@@ -351,7 +351,8 @@ def run_rank(args):
             "moves_per_sec": tot["moves"] / elapsed,
             "terminal_sim_fraction": tot["terminal_sims"] / max(1.0, sims),
             "bad_evals": tot["bad_evals"],
-            "net_evals_per_sec": (tot["leaf_evals"] - tot["eval_cache_hits"]) / elapsed,
+            "net_evals_per_sec": (tot["leaf_evals"] - tot["eval_cache_hits"] + tot.get("speculative_evals", 0)) / elapsed,
+            "speculative_evals_per_sec": tot.get("speculative_evals", 0) / elapsed,
             "eval_cache_hit_rate": tot["eval_cache_hits"] / max(1.0, tot["eval_cache_probes"]),
             "mean_leaf_depth": tot["depth_sum"] / max(1.0, sims),
             "timed_region_s": elapsed,
@@ -387,7 +388,7 @@ def run_rank(args):
             n_launch = args.steps
             launch_ms = timed_gpu_ms / n_launch
             r_sims = delta["simulations"] / n_launch
-            r_evals = (delta["leaf_evals"] - delta["eval_cache_hits"]) / n_launch
+            r_evals = (delta["leaf_evals"] - delta["eval_cache_hits"] + delta.get("speculative_evals", 0)) / n_launch
             r_depth = delta["depth_sum"] / max(1, delta["simulations"])
             tree_b = tree_bytes_per_sim(r_depth) * r_sims
             ach = tree_b / (launch_ms * 1e-3) / 1e9

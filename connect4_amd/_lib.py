@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("C4_ENGINE_LIB") or os.path.join(_HERE, "libc4engine.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "c4_engine.h")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OK, EINVAL, EDEVICE, ENOMEM, ESTATE, ECAPACITY = 0, -1, -2, -3, -4, -5
 RESULT_NONE, RESULT_XWIN, RESULT_DRAW, RESULT_OWIN = -1, 0, 1, 2
 EVAL_EXTERNAL_F32, EVAL_EXTERNAL_F64, EVAL_CENTRE = 0, 1, 2
@@ -41,7 +41,7 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "simulations", "expansions", "children_created", "terminal_sims", "leaf_evals", "depth_sum",
         "moves", "games_started", "games_finished", "launches", "active_slots", "capped_slots",
-        "eval_cache_hits", "eval_cache_probes", "bad_evals", "dropped_games")]
+        "eval_cache_hits", "eval_cache_probes", "bad_evals", "dropped_games", "speculative_evals")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define C4_ABI_VERSION 2
+#define C4_ABI_VERSION 3
 
 /* error codes */
 #define C4_OK 0
@@ -127,6 +127,9 @@ typedef struct {
                                    asserts instead (model.py:258-263); must be 0 in a healthy run */
     int64_t dropped_games;      /* finished games that found the record ring full (nobody drained or exported
                                    for record_capacity_games games) and were not recorded; 0 in a healthy run */
+    int64_t speculative_evals;  /* c4_selfplay_steps: network passes on positions evaluated ahead of the search (the
+                                   best-prior child of a fresh expansion) and put into the evaluation cache; not part
+                                   of leaf_evals -- network passes in total = leaf_evals - eval_cache_hits + this */
 } c4_stats;
 
 /* Root read-out of one slot (tree.py:66-117; what MCTS.make_move returns, mcts.py:88). */

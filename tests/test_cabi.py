@@ -36,7 +36,7 @@ def test_exports_every_declared_symbol(lib):
 def test_struct_sizes_match_header(lib):
     # c4_game_record / c4_root_result cross the ABI by value: sizes must match the C layout
     assert ctypes.sizeof(lib.GameRecord) == 8 + 4 + 4 + 42 * 8 * 2 + 42 * 4 + 42 * 8 + 42 * 7 * 8
-    assert ctypes.sizeof(lib.Stats) == 16 * 8
+    assert ctypes.sizeof(lib.Stats) == 17 * 8
     assert ctypes.sizeof(lib.ExportBuffers) == 9 * 8
     assert ctypes.sizeof(lib.Config) % 8 == 0
 

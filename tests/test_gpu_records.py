@@ -148,6 +148,39 @@ def test_eval_cache_lookup_returns_the_nets_answers():
     net.close()
 
 
+def test_speculative_evaluations_are_the_nets_answers(oracle):
+    """The split kernel's network waves evaluate positions ahead of the search (the best-prior child of a position they
+    just answered) and insert them into the evaluation cache.  That is invisible to the search only if such an entry
+    holds exactly what the evaluator answers for that position: every cached child of every recorded root -- entries
+    written by real requests and by speculative passes alike -- must equal the wave-private forward bit for bit."""
+    sp, net = _selfplay(32, 24, 64, 64, seed=9, eval_cache_log2_entries=22)
+    for _ in range(400):
+        sp.run_steps(64)
+        if sp.stats()["active_slots"] == 0:
+            break
+    st = sp.stats()
+    assert st["speculative_evals"] > 0
+    recs = sp.engine.drain_games()
+    kids0, kids1 = [], []
+    for r in recs:
+        for i in range(r.length):
+            b = oracle.Board.from_bits(int(r.color0[i]), int(r.color1[i]))
+            m = b.valid_mask()
+            for c in range(7):
+                if (m >> c) & 1:
+                    k = b.copy()
+                    k.make_move(c)
+                    kids0.append(k.key()[0])
+                    kids1.append(k.key()[1])
+    c0, c1 = np.array(kids0, dtype=np.uint64), np.array(kids1, dtype=np.uint64)
+    v, p, found = sp.engine.cache_lookup(c0, c1)
+    assert found.sum() > 1000
+    nv, npri = net.evaluate_bits(c0, c1, wave=True)
+    assert np.array_equal(v[found], nv[found]) and np.array_equal(p[found], npri[found])
+    sp.close()
+    net.close()
+
+
 def _sharded_worker(rank, world, port, q):
     import os
     import torch.distributed as dist

@@ -321,7 +321,9 @@ const char *c4_net_last_error(void);
  * no kernel boundary and no global barrier; slot state, leaves and answers stay in LDS for the whole
  * launch.  Default (split kernel): on every CU four tree waves own the workgroup's 16 (32) slots and walk their
  * trees; a slot that needs the evaluator posts its leaf in LDS and idles while its wave's other slots walk on;
- * four network waves claim posted leaves, run the forward and write the answer back -- no workgroup barrier;
+ * four network waves claim posted leaves, run the forward and write the answer back (and, when no leaf waits,
+ * evaluate the best-prior child of the position just answered into the evaluation cache: c4_stats.speculative_evals)
+ * -- no workgroup barrier;
  * a "step" is a time quantum of c4_config.time_budget_cycles shader cycles (80,000 if 0) and the launch runs
  * for n_steps quanta, however many simulations the trees needed per network answer.  With the environment
  * variable C4_FUSED_MODE=wave: every wave owns 2 (4) slots and alternates their tree walk with the network on

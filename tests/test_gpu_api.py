@@ -202,6 +202,42 @@ def test_fused_selfplay_kernel_equals_separate_kernels(monkeypatch):
     assert out[0][1]["bad_evals"] == 0
 
 
+@pytest.mark.parametrize("cache_bits", [-1, 8, 0])
+def test_split_kernel_edge_cases_play_the_same_games(monkeypatch, cache_bits):
+    """Tree waves + network waves against the wave-autonomous kernel where their hand-off is stressed: no evaluation
+    cache at all (every leaf goes to a network wave; no speculation), a 256-entry cache (constant eviction, speculative
+    inserts overwrite real ones and vice versa), the default cache; 19 slots (one full and one ragged workgroup, tree
+    waves with 0..1 slots), more slots than games (slots park while others still play), launches of a single quantum
+    (every launch ends with leaves in flight that the next one must pick up).  Same seed => same games, id by id."""
+    from connect4_amd.config import MCTSConfig
+    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.net import random_init_state_dict
+    from connect4_amd.selfplay import SelfPlay
+    net = FusedNet(random_init_state_dict(seed=0))
+    cfg = MCTSConfig.self_play(32)
+    out = []
+    for mode in ("wave", "split"):
+        monkeypatch.setenv("C4_FUSED_MODE", mode)
+        sp = SelfPlay(net, 19, cfg, seed=5, games_target=12, record_capacity_games=32, use_graph=False,
+                      fused_loop=True, steps_per_launch=1, eval_cache_log2_entries=cache_bits, time_budget_cycles=20000)
+        for _ in range(4000):
+            sp.run_steps(1)
+            if sp.stats()["active_slots"] == 0:
+                break
+        games = sorted(sp.drain(), key=lambda g: g.game_id)
+        st = sp.stats()
+        sp.close()
+        assert len(games) == 12 and st["bad_evals"] == 0
+        if mode == "split" and cache_bits >= 0:
+            assert st["speculative_evals"] > 0
+        if cache_bits < 0:
+            assert st["speculative_evals"] == 0 and st["eval_cache_hits"] == 0
+        out.append(([(g.game_id, g.moves, g.result.value, g.values, [list(p) for p in g.priors]) for g in games],
+                    {k: st[k] for k in ("simulations", "expansions", "moves", "games_finished", "terminal_sims", "leaf_evals")}))
+    assert out[0] == out[1]
+    net.close()
+
+
 def test_mini_generation_selfplay_train_reload(tmp_path):
     """BASELINE configs[4] flow at toy size on one GPU: fused self-play -> data.pth -> train step ->
     checkpoint -> the next generation's self-play runs on the updated weights."""

@@ -41,7 +41,15 @@ json.dump({"kernel": "c4_selfplay_split_kernel<16, f16, 4>",
 for src, dst in (("bench_final", "r02_bench_final"), ("bench_driver_args", "r02_bench_driver_args"), ("bench_8192", "r02_bench_8192_slots"),
                  ("bench_8192x3200", "r02_bench_8192x3200"), ("bench_64f", "r02_bench_64f_6res"), ("generation", "r02_generation_1gpu_share")):
     shutil.copy(os.path.join(O, src + ".json"), os.path.join(P, dst + ".json"))
-shutil.copy(glob.glob(os.path.join(O, "prof", "*", "*kernel_stats.csv"))[0], os.path.join(P, "r02_kernel_stats_final.csv"))
+shutil.copy(max(glob.glob(os.path.join(O, "prof", "*", "*kernel_stats.csv")), key=os.path.getmtime), os.path.join(P, "r02_kernel_stats_final.csv"))   # the newest run
+t = json.load(open(os.path.join(P, "r02_pmc_traffic.json")))
+for name in ("r02_bench_final", "r02_bench_driver_args"):
+    fn = os.path.join(P, name + ".json")
+    dd = json.load(open(fn))
+    dd["roofline"]["traffic"] = (2.0 * t["FETCH_SIZE_fused"] + t["WRITE_SIZE_fused"]) * 1024.0
+    dd["roofline"]["traffic_source"] = "profiles/r02_pmc_traffic.json (PMC passes of the same tools/final_measure.sh run, collected after this line was printed)"
+    json.dump(dd, open(fn, "w"))
+b = json.load(open(os.path.join(P, "r02_bench_final.json")))
 r = b["roofline"]
 print("bench_final: %.1f M exp/s, %.1f M sims/s, %.0f games/s, hit %.3f" % (b["value"] / 1e6, b["sims_per_sec"] / 1e6, b["games_per_sec"], b["eval_cache_hit_rate"]))
 print("roofline:", {k: r[k] for k in ("achieved", "frac", "traffic", "avg_launch_ms", "sims_per_launch", "algorithmic_bytes_per_launch", "mfma_achieved_tflops")})

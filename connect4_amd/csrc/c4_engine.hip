@@ -53,6 +53,9 @@
 #ifndef C4_SPECULATE
 #define C4_SPECULATE 1         // split kernel: a network wave with nothing else to do evaluates the best-prior child of the position it just answered (tuning aid: 0 = off)
 #endif
+#ifndef C4_SPLIT_PHASES
+#define C4_SPLIT_PHASES 0       // diagnostic build only: per-slot cycles per phase of the split kernel's tree walk (tools/split_stamps.py)
+#endif
 #ifndef C4_SPLIT_PAIRS
 #define C4_SPLIT_PAIRS 1      // split kernel: a network wave takes two waiting requests into one pass (tuning aid: 0 = one position per pass)
 #endif
@@ -698,7 +701,14 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
     int inner = 0;
     const unsigned long long wave_mask0 = WAVE_SYNC ? __builtin_amdgcn_ballot_w64(true) : 0ull;
     bool waiting = false;   // SPLIT: the leaf is with the network waves
+#if C4_SPLIT_PHASES
+    unsigned long long ph_t0 = 0, ph_iter = 0, ph_wait = 0, ph_apply = 0, ph_levels = 0, ph_n = 0, ph_ta = 0;
+    bool ph_was_waiting = false;
+#endif
     for (;;) {
+#if C4_SPLIT_PHASES
+        if (SPLIT) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); if (ph_t0) { (ph_was_waiting ? ph_wait : ph_iter) += tn - ph_t0; ph_n += ph_was_waiting ? 0 : 1; } ph_t0 = tn; ph_was_waiting = waiting; }
+#endif
         if (SPLIT) {
             if (__builtin_amdgcn_ballot_w64(!waiting) == 0) __builtin_amdgcn_s_sleep(4);   // nobody in this wave can walk
             if (waiting) {
@@ -714,6 +724,9 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
         }
         // ---------------------------------------------------------------- evaluate_node + expand + backup
         if (apply_now) {
+#if C4_SPLIT_PHASES
+            ph_ta = __builtin_amdgcn_s_memtime();
+#endif
             apply_now = false;
             if (fresh_eval) {   // evaluators.py:21-24: position_table[key] = evaluate_fn(board)
                 fresh_eval = false;
@@ -810,6 +823,9 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             pend = -1;
             group_fence();
             stamp(2);
+#if C4_SPLIT_PHASES
+            ph_apply += __builtin_amdgcn_s_memtime() - ph_ta;
+#endif
         }
 
         // ---------------------------------------------------------------- new root (Tree(board), tree.py:62-64)
@@ -983,6 +999,9 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             if (lane == 0) s_path[gl][0] = PathEntry{0u, cN, cW};
         }
         int age = popc64(b0 | b1);
+#if C4_SPLIT_PHASES
+        const unsigned long long ph_tl = __builtin_amdgcn_s_memtime();
+#endif
         unsigned long long lvl_t0 = (STAMPS && d.has_stamps) ? __builtin_amdgcn_s_memtime() : 0, lvl_wait = 0, lvl_alu = 0, lvl_cnt = 0;
 #if C4_EARLY_REQUEST
         // Software-pipelined level loop: the sibling block (and score-table entry) of the NEXT level is requested
@@ -1133,6 +1152,9 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             pinfo = cinfo;
             break;
         }
+#if C4_SPLIT_PHASES
+        ph_levels += __builtin_amdgcn_s_memtime() - ph_tl;
+#endif
         st.depth_sum += depth;
         stamp(3);
         const uint32_t lst = info_status(cinfo);
@@ -1232,6 +1254,9 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             sm->ply = ply;
             sm->gid = gid;
             sm->flags = SlotMem::pack(state, has_leaf, need_root);
+#if C4_SPLIT_PHASES
+            if (SPLIT && d.has_stamps && g < 256) { unsigned long long *o = d.cold->stamps + (size_t)g * 8; o[0] = ph_iter; o[1] = ph_wait; o[2] = ph_apply; o[3] = ph_levels; o[4] = ph_n; }
+#endif
             const uint32_t *sv = (const uint32_t *)&st;   // counters: per workgroup, flushed once per launch
 #pragma unroll
             for (int i = 0; i < N_STATS; ++i)
@@ -1739,7 +1764,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
             }
         }
     }
-    if (d.has_stamps && blockIdx.x < 128 && (threadIdx.x & 63) == 0) {   // per wave: busy cycles (tree waves 0..3, network waves 8..11 | passes << 48)
+    if (!C4_SPLIT_PHASES && d.has_stamps && blockIdx.x < 128 && (threadIdx.x & 63) == 0) {   // per wave: busy cycles (tree waves 0..3, network waves 8..11 | passes << 48)
         d.cold->stamps[blockIdx.x * 16 + (is_tree ? 0 : 8) + role_idx] = t_busy | (n_pass << 48);
         d.cold->stamps[blockIdx.x * 16 + (is_tree ? 4 : 12) + role_idx] = (unsigned long long)simd | ((unsigned long long)even << 8);
     }

@@ -1449,7 +1449,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
     __shared__ float s_pri[TS * 7];
     __shared__ uint32_t s_stats[N_STATS];
     __shared__ __attribute__((aligned(16))) float s_bias[BIAS_LDS_FLOATS];   // stem + conv biases (when the tower fits)
-    __shared__ __attribute__((aligned(16))) uint16_t s_tab16[(MODE != NETMODE_F64) ? 64 * TAB16 : 8];   // tap offsets of net_forward_wave16
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab16[64 * TAB16];   // tap offsets of the 16-row forwards
     // 32-filter fp16 net (small planes): per slot and for the whole launch, LDS of its own for the descent path of the
     // simulation in flight (a leaf that waits for the network needs no copy of its path in global memory) and for the
     // root's sibling block (hot subtree).  The wider planes of the other modes leave no room: there the path stacks
@@ -1483,7 +1483,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
     }
     for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
     stage_bias_lds(nd, s_bias);
-    if (MODE != NETMODE_F64 && threadIdx.x < 64) build_tab16(s_tab16, threadIdx.x);
+    if (threadIdx.x < 64) build_tab16<MODE == NETMODE_F64 ? CS64 : CS16>(s_tab16, threadIdx.x);
     if (OWN_PATH)
         for (int i = threadIdx.x; i < TS * MAX_DEPTH; i += NTHREADS) {   // paths of leaves pending from the previous launch
             const int p = i / MAX_DEPTH, k = i - p * MAX_DEPTH;
@@ -1600,7 +1600,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
     __shared__ float s_pri[(TS + NW) * 7];
     __shared__ uint32_t s_stats[N_STATS];
     __shared__ __attribute__((aligned(16))) float s_bias[BIAS_LDS_FLOATS];
-    __shared__ __attribute__((aligned(16))) uint16_t s_tab16[(MODE != NETMODE_F64) ? 64 * TAB16 : 8];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab16[64 * TAB16];
     __shared__ __attribute__((aligned(16))) PathEntry s_path[TS][MAX_DEPTH];   // every slot's descent path, for the whole launch
     __shared__ __attribute__((aligned(16))) Rec s_l1[TS][GROUP];               // every slot's root block
     __shared__ uint32_t s_req[TS];     // REQ_* of the slot's leaf
@@ -1633,7 +1633,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
     }
     for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
     stage_bias_lds(nd, s_bias);
-    if (MODE != NETMODE_F64 && threadIdx.x < 64) build_tab16(s_tab16, threadIdx.x);
+    if (threadIdx.x < 64) build_tab16<MODE == NETMODE_F64 ? CS64 : CS16>(s_tab16, threadIdx.x);
     for (int i = threadIdx.x; i < TS * MAX_DEPTH; i += NTHREADS) {   // paths of leaves pending from the previous launch
         const int p = i / MAX_DEPTH, k = i - p * MAX_DEPTH;
         if (slot0 + p < d.G) s_path[p][k] = d.path[(size_t)(slot0 + p) * MAX_DEPTH + k];

@@ -22,11 +22,11 @@
 //   * storage fp16, accumulation fp32 (same 10-bit mantissa as the TF32 path cuDNN uses by default
 //     for the reference's convs on its own GPU); heads and MLPs in fp32 on the VALU.
 //
-// Several forwards share this arithmetic (bit-identical answers): net_forward_block (above; c4_net_forward, the
-// workgroup-synchronous self-play kernel), net_forward_wave16 (one wave = one position on 16-row MFMA tiles,
-// private LDS planes, weights streamed from L2 into registers, no workgroup barrier; c4_net_forward_wave and the
-// wave-autonomous self-play kernel) and net_forward_wave1 (the general one-position form: 64 filters, and the
-// reference-precision mode of the 32-filter net).  All live in c4_net_dev.h.
+// Several forwards share this arithmetic: net_forward_block (above; c4_net_forward for the 32-filter fp16 net, the
+// workgroup-synchronous self-play kernel) and the wave-private forwards on 16-row MFMA tiles -- one wave = one position,
+// private LDS planes, weights streamed from L2 into registers, no workgroup barrier: net_forward_wave16 (32 filters, fp16;
+// bit-identical to the block forward; c4_net_forward_wave and the self-play kernels), net_forward_wave16p (32 filters,
+// reference precision), net_forward_wave16w (64 filters).  All live in c4_net_dev.h.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_kernel(NetDev nd, const uint6
     net_forward_block(nd, NetLds{lds, wbuf, mlp}, c0, c1, n, blockIdx.x * P, values, priors);
 }
 
-// One-position wave-private forward (net_forward_wave16p: reference precision at 32 filters; net_forward_wave1: fp16 at
+// One-position wave-private forward (net_forward_wave16p: reference precision at 32 filters; net_forward_wave16w: fp16 at
 // 64 filters): one position per wave.  Both c4_net_forward and c4_net_forward_wave run this kernel for such a net (one
 // implementation, so the two entry points and the fused self-play kernel cannot disagree).
 template <int MODE>
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_wave1_kernel(NetDev nd, const
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[64 * TAB16];
     for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
     stage_bias_lds(nd, s_bias);
-    if (threadIdx.x < 64) build_tab16(s_tab, threadIdx.x);
+    if (threadIdx.x < 64) build_tab16<MODE == NETMODE_F64 ? CS64 : CS16>(s_tab, threadIdx.x);
     __syncthreads();
     const int wv = threadIdx.x >> 6;
     const int p = blockIdx.x * NWAVES + wv;
@@ -158,6 +158,7 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
     memset(&net->d, 0, sizeof(NetDev));
     const int R = desc->n_residuals;
     const int CB = FW / 32, KPT = FW / 16, KS = 9 * KPT;   // cout blocks, k-steps per tap, k-steps per layer
+    // (32x32x16 order: what net_forward_block, the 32-filter block kernel, reads)
     // A fragments in MFMA lane order: fragment (k-step s, cout block cb) at [(s * CB + cb) * 64 + lane][8]; lane l
     // holds cout 32 cb + (l & 31) and the 8 k's 16 s + 8 (l >> 5) + j.
     // ---- stem: k = tap*4 + ch (ch 3 zero), 48 = 3 k-steps
@@ -195,39 +196,40 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
                 const int ci = 16 * s + 8 * (l >> 5) + j, co = l & 31;
                 head[((size_t)s * 64 + l) * 8 + j] = (_Float16)(co < 3 ? desc->head_w[co * FW + ci] : 0.0f);
             }
-    // ---- the same weights in v_mfma_f32_16x16x32_f16 fragment order (net_forward_wave16, 32 filters):
+    // ---- the same weights in v_mfma_f32_16x16x32_f16 fragment order (the wave-private forwards, 32 and 64 filters):
     //      lane l holds cout 16 ct + (l & 15) and the 8 k's 8 (l >> 4) + j of the k-step
     std::vector<_Float16> stem16, conv16, head16, stem16l, conv16l, head16l;   // ...l: the scaled low parts
-    if (FW == 32) {
-        stem16.assign((size_t)4 * 64 * 8, (_Float16)0.0f);          // [k-step s][ct]: k = 32 s + 8 g + j = tap*4 + ch
-        conv16.assign((size_t)std::max(1, 2 * R) * 18 * 64 * 8, (_Float16)0.0f);   // [L][tap][ct]: cin = 8 g + j
-        head16.assign((size_t)64 * 8, (_Float16)0.0f);              // couts 0..2, cin = 8 g + j
+    {
+        const int CT = FW / 16, KS2 = FW / 32;   // cout tiles of 16, k-steps of 32 input channels per tap
+        stem16.assign((size_t)2 * CT * 64 * 8, (_Float16)0.0f);                              // [k-step s][ct]: k = 32 s + 8 g + j = tap*4 + ch
+        conv16.assign((size_t)std::max(1, 2 * R) * 9 * KS2 * CT * 64 * 8, (_Float16)0.0f);   // [L][tap][ks][ct]: cin = 32 ks + 8 g + j
+        head16.assign((size_t)KS2 * 64 * 8, (_Float16)0.0f);                                 // [ks]: couts 0..2, cin = 32 ks + 8 g + j
         stem16l = stem16; conv16l = conv16; head16l = head16;
         for (int s2 = 0; s2 < 2; ++s2)
-            for (int ct = 0; ct < 2; ++ct)
+            for (int ct = 0; ct < CT; ++ct)
                 for (int l = 0; l < 64; ++l)
                     for (int j = 0; j < 8; ++j) {
                         const int k = 32 * s2 + 8 * (l >> 4) + j, tap = k >> 2, ch = k & 3, co = 16 * ct + (l & 15);
-                        const size_t at = (((size_t)s2 * 2 + ct) * 64 + l) * 8 + j;
+                        const size_t at = (((size_t)s2 * CT + ct) * 64 + l) * 8 + j;
                         if (tap < 9 && ch < 3) split(desc->stem_w[((co * 3 + ch) * 3 + tap / 3) * 3 + tap % 3], stem16[at], stem16l[at]);
                     }
         for (int L = 0; L < 2 * R; ++L)
             for (int tap = 0; tap < 9; ++tap)
-                for (int ct = 0; ct < 2; ++ct)
-                    for (int l = 0; l < 64; ++l)
-                        for (int j = 0; j < 8; ++j) {
-                            const int ci = 8 * (l >> 4) + j, co = 16 * ct + (l & 15);
-                            const size_t at = ((((size_t)L * 9 + tap) * 2 + ct) * 64 + l) * 8 + j;
-                            split(desc->conv_w[((((size_t)L * FW + co) * FW + ci) * 3 + tap / 3) * 3 + tap % 3], conv16[at], conv16l[at]);
-                        }
-        for (int l = 0; l < 64; ++l)
-            for (int j = 0; j < 8; ++j) {
-                const int ci = 8 * (l >> 4) + j, co = l & 15;
-                if (co < 3) split(desc->head_w[co * FW + ci], head16[((size_t)l) * 8 + j], head16l[((size_t)l) * 8 + j]);
-            }
-    } else {
-        stem16.assign(8, (_Float16)0.0f); conv16.assign(8, (_Float16)0.0f); head16.assign(8, (_Float16)0.0f);
-        stem16l = stem16; conv16l = conv16; head16l = head16;
+                for (int ks = 0; ks < KS2; ++ks)
+                    for (int ct = 0; ct < CT; ++ct)
+                        for (int l = 0; l < 64; ++l)
+                            for (int j = 0; j < 8; ++j) {
+                                const int ci = 32 * ks + 8 * (l >> 4) + j, co = 16 * ct + (l & 15);
+                                const size_t at = (((((size_t)L * 9 + tap) * KS2 + ks) * CT + ct) * 64 + l) * 8 + j;
+                                split(desc->conv_w[((((size_t)L * FW + co) * FW + ci) * 3 + tap / 3) * 3 + tap % 3], conv16[at], conv16l[at]);
+                            }
+        for (int ks = 0; ks < KS2; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int ci = 32 * ks + 8 * (l >> 4) + j, co = l & 15;
+                    const size_t at = ((size_t)ks * 64 + l) * 8 + j;
+                    if (co < 3) split(desc->head_w[co * FW + ci], head16[at], head16l[at]);
+                }
     }
     std::vector<float> stem_b(desc->stem_b, desc->stem_b + FW), conv_b(desc->conv_b, desc->conv_b + (size_t)2 * R * FW),
         head_b(4, 0.0f), mlp((size_t)MLP_F4 * 4, 0.0f);

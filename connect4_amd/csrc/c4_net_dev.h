@@ -429,24 +429,13 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
 // from L2 (the whole net is ~110 KB) into registers ahead of their use; per-element arithmetic (bias as the
 // accumulator's initial value, k order, identity-MFMA skip, epilogue, heads, MLPs) is net_forward_block's,
 // so all forwards of one net give bit-identical answers (tests/test_gpu_fused_net.py).
-//   net_forward_wave16          32 filters, fp16 storage: the self-play kernel's hot forward (16-row MFMA tiles)
-//   net_forward_wave1<FW, P>    general form on 32-row tiles: 64 filters, and reference precision at 32 filters
-// (Rounds 1-2 also had a two-position forward on 32-row tiles, 34 k cycles per pass against 27 k for one
-// position; inside the fused kernel almost every pass has ONE leaf, and a second row cost ~1.5x there.)
+// All of them run on 16-row MFMA tiles (v_mfma_f32_16x16x32_f16: the position's 42 pixels are 3 row tiles):
+//   net_forward_wave16n<NP>     32 filters, fp16 storage: the self-play kernels' hot forward, NP positions per pass
+//   net_forward_wave16p         32 filters, reference precision (fp16 hi + lo split)
+//   net_forward_wave16w         64 filters, fp16 storage
+// (Earlier rounds had forwards on 32-row tiles -- two positions per pass, then one position in two half-empty tiles:
+// 22-27 k cycles per pass at 32 filters where the 16-row forward takes 17-20 k; retired.)
 // ------------------------------------------------------------------------------------------------
-constexpr int WACT = (96 + 1) * CS;          // halves of one of a wave's two private buffers as the general forward sizes them (7,760 B)
-
-// ------------------------------------------------------------------------------------------------
-// One-position wave-private forward on 32-row tiles, net_forward_wave1<FW>: the general form of the wave-private
-// forward -- any supported width FW (32 or 64 filters = 1 or 2 cout blocks of 32 per MFMA), fp16 storage -- for ONE
-// position per pass.  It serves the 64-filter net; the 32-filter nets run the tuned 16-row-tile forwards below
-// (net_forward_wave16, and net_forward_wave16p for the reference-precision mode).
-//   * rows: the position's 42 pixels in two 32-row MFMA tiles; rows 42..63 read the zero row and are never
-//     stored, so a plane needs 43 rows of FW + 8 halves: ping/pong planes of 64 filters are 2 x 6,192 B;
-//   * weights: fragments stream from L2 through a rolling window of WDEPTH k-steps (the tower's k-steps are
-//     one linear sequence in memory, so the window rolls across layer boundaries);
-//   * heads and MLPs as in net_forward_block (fp32 VALU).
-//
 // Reference precision (C4_NET_F32X3, net_forward_wave16p): every fp32 operand x (folded weight, activation) is
 // carried as two fp16 numbers
 //     x  ~=  hi + lo / 2^11,      hi = f16(x),   lo = f16((x - hi) * 2^11)
@@ -456,281 +445,8 @@ constexpr int WACT = (96 + 1) * CS;          // halves of one of a wave's two pr
 // dropped.  Operand error 2^-22, products exact, sums in fp32: the class of an fp32 convolution whose
 // summation order differs (what the PyTorch-ROCm / MIOpen plan is against the reference's CPU convs).
 // The input planes are 0/1 (exact in fp16), so the stem needs two MFMAs per k-step, every other layer three.
-// ------------------------------------------------------------------------------------------------
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
 constexpr int PROWS = PIX + 1;               // 42 real rows + the zero row
-constexpr int WDEPTH = 6;                    // k-steps of weights in flight (divides the k-steps of a layer: a k-step's window slot is s % 6 in every layer)
-template <int FW> struct Wave1Geom {
-    static constexpr int CB = FW / 32;            // cout blocks of 32 (one MFMA each)
-    static constexpr int KPT = FW / 16;           // k-steps per tap
-    static constexpr int KS = 9 * KPT;            // k-steps per 3x3 conv layer
-    static constexpr int CSF = FW + 8;            // halves per LDS row: (FW + 8) * 2 B keeps ds_read_b128 conflict free for 32 and 64
-    static constexpr int PLANE = PROWS * CSF;     // halves per plane
-    static_assert(FW == 32 || FW == 64, "supported widths");
-    static_assert(KS % WDEPTH == 0, "rolling weight window");
-};
-
-template <int FW>
-__device__ __forceinline__ void wave1_store(const floatx16 &hi, _Float16 *dh, int off, bool real)
-{
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        half4 oh;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) oh[i] = (_Float16)lrelu(hi[4 * q + i]);
-        if (real) *reinterpret_cast<half4 *>(dh + off + 8 * q) = oh;
-    }
-}
-
-template <int FW>
-__device__ __forceinline__ void net_forward_wave1(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds,
-                                                  uint64_t b0, uint64_t b1, float *__restrict__ values,
-                                                  float *__restrict__ priors, int out, unsigned long long *stamps = nullptr)
-{
-    using G = Wave1Geom<FW>;
-    constexpr int CB = G::CB, KPT = G::KPT, KS = G::KS, CSF = G::CSF, PLANE = G::PLANE;
-    static_assert(2 * PLANE <= 2 * WACT, "planes must fit the wave's two private buffers");
-    int lane_ = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane_));     // inside a persistent kernel the compiler would otherwise hoist every lane-derived address of this function out of the caller's step loop, keep them live across the tree walk and reload them from scratch mid-pass
-    const int lane = lane_;
-    const int r32 = lane & 31, h = lane >> 5;
-    auto stamp = [&](int i) { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); };
-    stamp(0);
-    const int n_layers = 2 * nd.n_res;
-    // planes: ping (p0) and pong (p1)
-    _Float16 *const p0h = buf, *const p1h = buf + PLANE;
-    auto load_bias = [&](const float *b, float4 (&o)[CB][4]) {
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o[cb][q] = *reinterpret_cast<const float4 *>(b + 32 * cb + 8 * q + 4 * h);
-    };
-    // rolling weight window, primed with the first WDEPTH k-steps of the tower; fragment (k-step t, cout block cb)
-    // lives at [(t * CB + cb) * 64 + lane]
-    half8 wh[WDEPTH][CB];
-    const half8 *wph = nd.conv_w + lane;
-    const int total_steps = n_layers * KS;
-#pragma unroll
-    for (int s = 0; s < WDEPTH; ++s) {
-        const int t = s < total_steps ? s : 0;
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) wh[s][cb] = wph[(t * CB + cb) * 64];
-    }
-    half8 swh[3][CB];
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) swh[s][cb] = nd.stem_w[(s * CB + cb) * 64 + lane];
-    float4 bias[CB][4];
-    load_bias(bias_lds, bias);
-    // input planes (board.py:147-154), 4 halves per row, at the start of p1h (the tower writes it only after the stem)
-    _Float16 *inp = p1h;
-    if (lane <= PIX) {
-        half4 v = {};
-        if (lane < PIX) {
-            const int y = lane / 7, x = lane - y * 7;
-            const int bit = x * 7 + (5 - y);
-            v[0] = (_Float16)((__popcll(b0 | b1) & 1) ? 0.0f : 1.0f);
-            v[1] = (_Float16)(float)((b0 >> bit) & 1);
-            v[2] = (_Float16)(float)((b1 >> bit) & 1);
-        }
-        *reinterpret_cast<half4 *>(inp + lane * 4) = v;   // lane == PIX: the zero row of the planes
-    }
-    for (int i = lane; i < CSF; i += 64) {   // the zero rows of the planes (the input planes occupy the first rows of p1h only)
-        p0h[PIX * CSF + i] = (_Float16)0.0f;
-        p1h[PIX * CSF + i] = (_Float16)0.0f;
-    }
-    // row geometry: tile ti holds rows 32 ti + r32; rows >= 42 read the zero row and store nothing
-    uint32_t rsel2[2][5];
-    int rbase[2];
-    bool real[2];
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-        const int rg = ti * 32 + r32;
-        const int y = rg / 7, x = rg - y * 7;
-        real[ti] = rg < PIX;
-        rbase[ti] = (real[ti] ? rg : PIX) * CSF;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) rsel2[ti][j] = 0;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            const int ok = -(int)(real[ti] && (unsigned)(y + dy) < 6u && (unsigned)(x + dx) < 7u);
-            const uint32_t off = (uint32_t)((((rg + dy * 7 + dx) & ok) | (PIX & ~ok)) * CSF + 8 * h);
-            rsel2[ti][tap >> 1] |= off << (16 * (tap & 1));
-        }
-    }
-    auto rsel = [&](int ti, int tap) -> int { return (int)((rsel2[ti][tap >> 1] >> (16 * (tap & 1))) & 0xffffu); };
-    // ------------------------------------------------------------------ stem: planes -> p0
-    {
-        floatx16 ah[2][CB];
-        half4 v[2][6];
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
-            const int rg = ti * 32 + r32;
-            const int y = rg / 7, x = rg - y * 7;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int tap = 4 * (i >> 1) + 2 * h + (i & 1);
-                const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;
-                const int ok = -(int)(real[ti] && tap < 9 && (unsigned)(y + ty - 1) < 6u && (unsigned)(x + tx - 1) < 7u);
-                const int row = ((rg + (ty - 1) * 7 + tx - 1) & ok) | (PIX & ~ok);
-                v[ti][i] = *reinterpret_cast<const half4 *>(inp + row * 4);
-            }
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) ah[ti][cb] = acc_from_bias(bias[cb]);
-        }
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                half8 bf;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { bf[j] = v[ti][2 * s][j]; bf[4 + j] = v[ti][2 * s + 1][j]; }
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) ah[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(swh[s][cb], bf, ah[ti][cb], 0, 0, 0);
-            }
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-                wave1_store<FW>(ah[ti][cb], p0h, rbase[ti] + 32 * cb + 4 * h, real[ti]);
-    }
-    stamp(1);
-    // ------------------------------------------------------------------ residual tower
-    for (int L = 0; L < n_layers; ++L) {
-        const bool second = L & 1;
-        const _Float16 *sh = second ? p1h : p0h;
-        _Float16 *dh = second ? p0h : p1h;
-        floatx16 ah[2][CB];
-        load_bias(bias_lds + FW * (1 + L), bias);
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) ah[ti][cb] = acc_from_bias(bias[cb]);
-        half8 bh[2], nh[2];
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti) bh[ti] = *reinterpret_cast<const half8 *>(sh + rsel(ti, 0));
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            if (s + 1 < KS) {
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti) {
-                    const int o = rsel(ti, (s + 1) / KPT) + ((s + 1) % KPT) * 16;
-                    nh[ti] = *reinterpret_cast<const half8 *>(sh + o);
-                }
-            }
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) {
-                const half8 cwh = wh[s % WDEPTH][cb];
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti) ah[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh, bh[ti], ah[ti][cb], 0, 0, 0);
-            }
-            {   // refill the window slot just used with k-step (L*KS + s + WDEPTH) of the tower; unconditional
-                // (past the end it re-reads step 0: a branch around the loads would drain vmcnt)
-                int t = L * KS + s + WDEPTH;
-                t = t < total_steps ? t : 0;
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) wh[s % WDEPTH][cb] = wph[(t * CB + cb) * 64];
-            }
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti) bh[ti] = nh[ti];
-        }
-        if (second) {   // + block input (lives in dh): identity MFMAs add it exactly
-            half8 idf[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) idf[s][j] = (_Float16)((16 * s + 8 * h + j) == r32 ? 1.0f : 0.0f);
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    const int o = rbase[ti] + 32 * cb + 8 * h;
-                    const half8 xh0 = *reinterpret_cast<const half8 *>(dh + o), xh1 = *reinterpret_cast<const half8 *>(dh + o + 16);
-                    ah[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[0], xh0, ah[ti][cb], 0, 0, 0);
-                    ah[ti][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(idf[1], xh1, ah[ti][cb], 0, 0, 0);
-                }
-        }
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-                wave1_store<FW>(ah[ti][cb], dh, rbase[ti] + 32 * cb + 4 * h, real[ti]);
-        if (L < 6) stamp(2 + L);
-    }
-    stamp(8);
-    // tower output is in p0 (n_layers is even)
-    // ------------------------------------------------------------------ 1x1 head convs (K = FW: KPT k-steps)
-    float *hs = reinterpret_cast<float *>(p1h);   // [HSTR] fp32: value plane 0..41, policy planes 42..125 (p1 is free)
-    {
-        const float hb0 = nd.head_b[0], hb1 = nd.head_b[1], hb2 = nd.head_b[2];
-        float o0[2], o1[2], o2[2];
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
-            floatx16 a = {};
-#pragma unroll
-            for (int s = 0; s < KPT; ++s) {
-                const half8 hwh = nd.head_w[s * 64 + lane];
-                const half8 xh = *reinterpret_cast<const half8 *>(p0h + rbase[ti] + 16 * s + 8 * h);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwh, xh, a, 0, 0, 0);
-            }
-            o0[ti] = lrelu(a[0] + hb0);
-            o1[ti] = lrelu(a[1] + hb1);
-            o2[ti] = lrelu(a[2] + hb2);
-        }
-        // every lane has read the tower output and p1 is dead: the head planes may overwrite p1h
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
-            const int rg = ti * 32 + r32;
-            if (h == 0 && rg < PIX) {
-                hs[0 * PIX + rg] = o0[ti];
-                hs[1 * PIX + rg] = o1[ti];
-                hs[2 * PIX + rg] = o2[ti];
-            }
-        }
-        if (lane < 2) hs[HEADV + lane] = 0.0f;   // pad 126,127
-    }
-    stamp(9);
-    // ------------------------------------------------------------------ MLP heads (fp32 VALU), as in net_forward_block
-    {
-        const float *vt_b = reinterpret_cast<const float *>(mlp + VT_F4 + PT_F / 4);   // fc_b | vout_w | pfc_b
-        const float *pt = reinterpret_cast<const float *>(mlp + VT_F4);
-        const float4 *hA4 = reinterpret_cast<const float4 *>(hs);
-        float v0 = 0.0f;
-#pragma unroll
-        for (int g = 0; g < 11; ++g) {
-            const float4 wv = mlp[g * 64 + lane];
-            const float4 xa = hA4[g];
-            v0 += wv.x * xa.x + wv.y * xa.y + wv.z * xa.z + wv.w * xa.w;
-        }
-        const int seg = lane >> 3;
-        const float *hpA = hs + PIX + seg * 11;
-        float l0 = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 11; ++c) {
-            const float wv = pt[c * 64 + lane];      // zero where seg*11 + c >= 84 or (lane & 7) == 7
-            const int cc = seg * 11 + c < 2 * PIX ? c : 2 * PIX - 1 - seg * 11;
-            l0 += wv * hpA[cc];
-        }
-        l0 += dppf<0x128>(l0);
-#pragma unroll
-        for (int m = 16; m <= 32; m <<= 1) l0 += __shfl_xor(l0, m, 64);
-        const float fb = vt_b[lane], vw = vt_b[64 + lane], pb = vt_b[128 + lane];
-        const bool is_pol = lane < 7;
-        const float a = v0 + fb;
-        const float lg = l0 + pb;
-        const float rs = sum16(lane < PIX ? vw * lrelu(a) : 0.0f);               // model.py:83-85
-        const float vsum = readlane_f(rs, 0) + readlane_f(rs, 16) + readlane_f(rs, 32);
-        const float value = (tanhf(vsum + nd.vout_b) + nd.w1) * nd.w2;           // model.py:86-88
-        const float mx = max8(is_pol ? lg : -INFINITY);
-        const float e = is_pol ? expf(lg - mx) : 0.0f;
-        const float sum = sum8(e);
-        if (lane == 0) values[out] = value;
-        if (is_pol) priors[(size_t)out * 7 + lane] = e / sum;
-    }
-    stamp(10);
-}
 
 // ------------------------------------------------------------------------------------------------
 // net_forward_wave16: the one-position wave-private forward of the 32-filter fp16 net on 16-row MFMA
@@ -758,12 +474,12 @@ constexpr int CS16 = 48;                       // halves per LDS row: 96-byte st
 constexpr int PLANE16 = PROWS * CS16;          // halves per plane (4,128 B)
 constexpr int RT16 = 3;                        // row tiles of 16
 constexpr int TAB16 = 40;                      // u16 per lane in the tap-offset table: 27 tower taps + 12 stem taps + pad
-static_assert(2 * PLANE16 <= 2 * WACT, "the two planes must fit the wave's private buffers");
 
 // tap-offset table, one row of TAB16 u16 per lane id (built once per launch by 64 threads of the workgroup):
 //   [rt*9 + tap]            offset in halves of (pixel row 16 rt + (l&15), tap) in a plane, + 8 (l>>4); the zero row
 //                           where the pixel is not real or the tap leaves the board
 //   [27 + rt*4 + s*2 + e]   stem: offset in halves (4 per row) of input-plane row for tap 8 s + 2 (l>>4) + e
+template <int CS = CS16>
 __device__ __forceinline__ void build_tab16(uint16_t *tab, int lane)
 {
     const int n = lane & 15, g = lane >> 4;
@@ -773,7 +489,7 @@ __device__ __forceinline__ void build_tab16(uint16_t *tab, int lane)
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
             const bool ok = real && (unsigned)(y + dy) < 6u && (unsigned)(x + dx) < 7u;
-            tab[lane * TAB16 + rt * 9 + tap] = (uint16_t)((ok ? r + 7 * dy + dx : PIX) * CS16 + 8 * g);
+            tab[lane * TAB16 + rt * 9 + tap] = (uint16_t)((ok ? r + 7 * dy + dx : PIX) * CS + 8 * g);
         }
         for (int s = 0; s < 2; ++s)
             for (int e = 0; e < 2; ++e) {
@@ -1050,7 +766,7 @@ __device__ __forceinline__ void net_forward_wave16(const NetDev &nd, _Float16 *b
 // the 16-row tiles of net_forward_wave16: 9 taps x 3 row tiles x 2 cout tiles x 3 = 162 MFMAs of 16 cycles per
 // layer instead of 108 of 32, four planes (ping/pong x hi/lo) of 43 rows x 96 bytes, the hi and lo weight
 // fragments of a tap stream from L2 through a rolling window of three taps (the tower's taps are one linear
-// sequence in memory).  Same accumulation per output element as net_forward_wave1<32, true>.
+// sequence in memory).
 // ------------------------------------------------------------------------------------------------
 constexpr int WTAPS = 3;   // taps of weights in flight (divides 9: a tap's window slot is t % 3 in every layer)
 
@@ -1296,6 +1012,230 @@ __device__ __forceinline__ void net_forward_wave16p(const NetDev &nd, _Float16 *
     stamp(10);
 }
 
+// ------------------------------------------------------------------------------------------------
+// net_forward_wave16w: the 64-filter net (data/example_config.py:8-16; fp16 storage) on the 16-row tiles of
+// net_forward_wave16: 9 taps x 2 k-steps of 32 input channels x 4 cout tiles x 3 row tiles = 216 MFMAs of 16 cycles per
+// layer (on 32-row tiles: 144 of 32), planes of 43 rows x 144 bytes (conflict free for the operand's ds_read_b128), the
+// four weight fragments of a (tap, k-step) unit stream from L2 through a rolling window of three units (the tower's units
+// are one linear sequence in memory).
+// ------------------------------------------------------------------------------------------------
+constexpr int CS64 = 72;                       // halves per LDS row at 64 filters: 144-byte stride
+constexpr int PLANE64 = PROWS * CS64;          // halves per plane (6,192 B)
+constexpr int WUNITS = 3;                      // (tap, k-step) units of weights in flight (divides 18: a unit's window slot is u % 3 in every layer)
+
+__device__ __forceinline__ void net_forward_wave16w(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds,
+                                                    const uint16_t *tab, uint64_t b0, uint64_t b1, float *__restrict__ values,
+                                                    float *__restrict__ priors, int out, unsigned long long *stamps = nullptr)
+{
+    constexpr int FW = 64, CT = 4, KS = 2;     // filters, cout tiles of 16, k-steps of 32 per tap
+    int lane_ = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_));     // keep lane-derived addresses out of a persistent caller's loop (see net_forward_wave16)
+    const int lane = lane_;
+    const int n = lane & 15, g = lane >> 4;
+    auto stamp = [&](int i) { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
+    const int n_layers = 2 * nd.n_res;
+    _Float16 *const p0 = buf, *const p1 = buf + PLANE64;
+    // rolling weight window: fragment (unit U = (L*9 + tap)*2 + ks of the tower, cout tile ct) at [(U * 4 + ct) * 64 + lane]
+    half8 w[WUNITS][CT];
+    const half8 *wp = nd.conv_w16 + lane;
+    const int total_units = n_layers * 18;
+#pragma unroll
+    for (int u = 0; u < WUNITS; ++u) {
+        const int U = u < total_units ? u : 0;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) w[u][ct] = wp[(U * CT + ct) * 64];
+    }
+    half8 sw[2][CT];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) sw[s][ct] = nd.stem_w16[(s * CT + ct) * 64 + lane];
+    const half8 hw0 = nd.head_w16[lane], hw1 = nd.head_w16[64 + lane];   // the heads' fragments and biases: requested a whole tower ahead
+    const float hb0 = nd.head_b[0], hb1 = nd.head_b[1], hb2 = nd.head_b[2];
+    uint32_t tb[TAB16 / 2];
+    {
+        const uint4 *t4 = reinterpret_cast<const uint4 *>(tab + lane * TAB16);
+#pragma unroll
+        for (int i = 0; i < TAB16 / 8; ++i) { const uint4 v = t4[i]; tb[4 * i] = v.x; tb[4 * i + 1] = v.y; tb[4 * i + 2] = v.z; tb[4 * i + 3] = v.w; }
+    }
+    auto tof = [&](int idx) -> int { return (int)((tb[idx >> 1] >> (16 * (idx & 1))) & 0xffffu); };
+    // input planes (board.py:147-154), 4 halves per row, at the start of p1 (the tower writes p1 only after the stem)
+    _Float16 *inp = p1;
+    if (lane <= PIX) {
+        half4 v = {};
+        if (lane < PIX) {
+            const int y = lane / 7, x = lane - y * 7;
+            const int bit = x * 7 + (5 - y);
+            v[0] = (_Float16)((__popcll(b0 | b1) & 1) ? 0.0f : 1.0f);
+            v[1] = (_Float16)(float)((b0 >> bit) & 1);
+            v[2] = (_Float16)(float)((b1 >> bit) & 1);
+        }
+        *reinterpret_cast<half4 *>(inp + lane * 4) = v;   // lane == PIX: the zero row of the planes
+    }
+    for (int i = lane; i < CS64; i += 64) { p0[PIX * CS64 + i] = (_Float16)0.0f; p1[PIX * CS64 + i] = (_Float16)0.0f; }
+    bool real[RT16];
+    int rbase[RT16];
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt) {
+        real[rt] = 16 * rt + n < PIX;
+        rbase[rt] = (real[rt] ? 16 * rt + n : PIX) * CS64;
+    }
+    auto bias4 = [&](const float *b, int ct) -> floatx4 {
+        const float4 v = *reinterpret_cast<const float4 *>(b + 16 * ct + 4 * g);
+        return floatx4{v.x, v.y, v.z, v.w};
+    };
+    // ------------------------------------------------------------------ stem: planes -> p0   (K = 36 -> two k-steps of 32)
+    {
+        floatx4 acc[RT16][CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const floatx4 bv = bias4(bias_lds, ct);
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) acc[rt][ct] = bv;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) {
+                const half4 va = *reinterpret_cast<const half4 *>(inp + tof(27 + rt * 4 + s * 2));
+                const half4 vb = *reinterpret_cast<const half4 *>(inp + tof(27 + rt * 4 + s * 2 + 1));
+                half8 bf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bf[j] = va[j]; bf[4 + j] = vb[j]; }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sw[s][ct], bf, acc[rt][ct], 0, 0, 0);
+            }
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) store16(acc[rt][ct], p0, rbase[rt] + 16 * ct + 4 * g, real[rt]);
+    }
+    stamp(1);
+    // ------------------------------------------------------------------ residual tower
+    for (int L = 0; L < n_layers; ++L) {
+        const bool second = L & 1;
+        const _Float16 *src = second ? p1 : p0;
+        _Float16 *dst = second ? p0 : p1;
+        floatx4 acc[RT16][CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const floatx4 bv = bias4(bias_lds + FW * (1 + L), ct);
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) acc[rt][ct] = bv;
+        }
+        half8 bc[RT16], bn[RT16];
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt) bc[rt] = *reinterpret_cast<const half8 *>(src + tof(rt * 9));
+#pragma unroll
+        for (int u = 0; u < 18; ++u) {   // unit u = (tap u / 2, k-step u % 2)
+            if (u + 1 < 18) {
+#pragma unroll
+                for (int rt = 0; rt < RT16; ++rt) bn[rt] = *reinterpret_cast<const half8 *>(src + tof(rt * 9 + (u + 1) / 2) + 32 * ((u + 1) % 2));
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const half8 cw = w[u % WUNITS][ct];
+#pragma unroll
+                for (int rt = 0; rt < RT16; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cw, bc[rt], acc[rt][ct], 0, 0, 0);
+            }
+            {   // refill the window slot just used with unit (L*18 + u + WUNITS) of the tower; unconditional (past the end it
+                // re-reads unit 0: a branch around the loads would drain vmcnt)
+                int U = L * 18 + u + WUNITS;
+                U = U < total_units ? U : 0;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) w[u % WUNITS][ct] = wp[(U * CT + ct) * 64];
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) bc[rt] = bn[rt];
+        }
+        if (second) {   // + block input (lives in dst): identity fragment of cout tile ct picks input channels 16 ct .. 16 ct + 15,
+                        // which sit in k-step ct / 2: A[cout n][cin 32 (ct / 2) + 8 g + j] = (8 g + j == 16 (ct % 2) + n)
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const half8 x = *reinterpret_cast<const half8 *>(dst + rbase[rt] + 32 * ks + 8 * g);
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        half8 idf;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) idf[j] = (_Float16)((8 * g + j) == 16 * c2 + n ? 1.0f : 0.0f);
+                        acc[rt][2 * ks + c2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(idf, x, acc[rt][2 * ks + c2], 0, 0, 0);
+                    }
+                }
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) store16(acc[rt][ct], dst, rbase[rt] + 16 * ct + 4 * g, real[rt]);
+        if (L < 6) stamp(2 + L);
+    }
+    stamp(8);
+    // tower output is in p0 (n_layers is even)
+    // ------------------------------------------------------------------ 1x1 head convs: couts 0..2 = rows 0..2 of a cout tile, two k-steps
+    float *hs = reinterpret_cast<float *>(p1);   // [HSTR] fp32: value plane 0..41, policy planes 42..125 (p1 is free)
+    {
+        floatx4 a[RT16];
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt) {
+            const half8 x0 = *reinterpret_cast<const half8 *>(p0 + rbase[rt] + 8 * g);
+            const half8 x1 = *reinterpret_cast<const half8 *>(p0 + rbase[rt] + 32 + 8 * g);
+            a[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hw0, x0, floatx4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+            a[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hw1, x1, a[rt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt) {
+            const int r = 16 * rt + n;
+            if (g == 0 && r < PIX) {      // couts 0..3 sit in the accumulators of lanes 0..15
+                hs[0 * PIX + r] = lrelu(a[rt][0] + hb0);
+                hs[1 * PIX + r] = lrelu(a[rt][1] + hb1);
+                hs[2 * PIX + r] = lrelu(a[rt][2] + hb2);
+            }
+        }
+        if (lane < 2) hs[HEADV + lane] = 0.0f;   // pad 126,127
+    }
+    stamp(9);
+    // ------------------------------------------------------------------ MLP heads (fp32 VALU), as in net_forward_block
+    {
+        const float *vt_b = reinterpret_cast<const float *>(mlp + VT_F4 + PT_F / 4);   // fc_b | vout_w | pfc_b
+        const float *pt = reinterpret_cast<const float *>(mlp + VT_F4);
+        const float4 *hA4 = reinterpret_cast<const float4 *>(hs);
+        float v0 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 11; ++q) {
+            const float4 wv = mlp[q * 64 + lane];
+            const float4 xa = hA4[q];
+            v0 += wv.x * xa.x + wv.y * xa.y + wv.z * xa.z + wv.w * xa.w;
+        }
+        const int seg = lane >> 3;
+        const float *hpA = hs + PIX + seg * 11;
+        float l0 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 11; ++c) {
+            const float wv = pt[c * 64 + lane];      // zero where seg*11 + c >= 84 or (lane & 7) == 7
+            const int cc = seg * 11 + c < 2 * PIX ? c : 2 * PIX - 1 - seg * 11;
+            l0 += wv * hpA[cc];
+        }
+        l0 += dppf<0x128>(l0);
+#pragma unroll
+        for (int m = 16; m <= 32; m <<= 1) l0 += __shfl_xor(l0, m, 64);
+        const float fb = vt_b[lane], vw = vt_b[64 + lane], pb = vt_b[128 + lane];
+        const bool is_pol = lane < 7;
+        const float a = v0 + fb;
+        const float lg = l0 + pb;
+        const float rs = sum16(lane < PIX ? vw * lrelu(a) : 0.0f);               // model.py:83-85
+        const float vsum = readlane_f(rs, 0) + readlane_f(rs, 16) + readlane_f(rs, 32);
+        const float value = (tanhf(vsum + nd.vout_b) + nd.w1) * nd.w2;           // model.py:86-88
+        const float mx = max8(is_pol ? lg : -INFINITY);
+        const float e = is_pol ? expf(lg - mx) : 0.0f;
+        const float sum = sum8(e);
+        if (lane == 0) values[out] = value;
+        if (is_pol) priors[(size_t)out * 7 + lane] = e / sum;
+    }
+    stamp(10);
+}
+
 // net mode of a NetDev, as the kernels are specialised
 constexpr int NETMODE_F32_F16 = 0;    // 32 filters, fp16 storage: net_forward_wave16 / net_forward_block
 constexpr int NETMODE_F32_PRECISE = 1;
@@ -1305,13 +1245,13 @@ __device__ __forceinline__ void net_forward_wave1_mode(const NetDev &nd, _Float1
                                                        const uint16_t *tab, uint64_t b0, uint64_t b1, float *__restrict__ values,
                                                        float *__restrict__ priors, int out, unsigned long long *stamps = nullptr)
 {
-    if (MODE == NETMODE_F64) net_forward_wave1<64>(nd, buf, mlp, bias_lds, b0, b1, values, priors, out, stamps);
+    if (MODE == NETMODE_F64) net_forward_wave16w(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, stamps);
     else if (MODE == NETMODE_F32_PRECISE) net_forward_wave16p(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, stamps);
     else net_forward_wave16(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, stamps);
 }
 // halves of private LDS a wave needs for its planes in each mode
 template <int MODE> struct WaveBuf {
-    static constexpr int HALVES = MODE == NETMODE_F64 ? 2 * WACT : (MODE == NETMODE_F32_PRECISE ? 4 * PLANE16 : 2 * PLANE16);
+    static constexpr int HALVES = MODE == NETMODE_F64 ? 2 * PLANE64 : (MODE == NETMODE_F32_PRECISE ? 4 * PLANE16 : 2 * PLANE16);
 };
 
 constexpr int BIAS_LDS_FLOATS = 32 * (1 + 32);    // 4.2 KB: stem + conv biases of up to 16 residual blocks at 32 filters, 7 at 64

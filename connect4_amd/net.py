@@ -33,9 +33,33 @@ class NetConfig:
         self.n_residuals = n_residuals
 
 
+class _BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters and state-dict keys) that can take its batch statistics from the first
+    `valid_rows` samples only.  The trainer pads the ragged last batch of an epoch to the full batch size -- every
+    convolution then runs the shape MIOpen has already compiled kernels for instead of a new one per generation (6-9 s
+    each) -- and sets valid_rows: the padding rows are normalised with the real rows' statistics, carry no loss, and so
+    change neither the activations of the real rows nor any gradient."""
+    valid_rows = None
+
+    def forward(self, x):
+        k = self.valid_rows
+        if k is None or not self.training:
+            return super().forward(x)
+        xs = x[:k]
+        mean = xs.mean(dim=(0, 2, 3))
+        var = xs.var(dim=(0, 2, 3), unbiased=False)
+        with torch.no_grad():      # running statistics as nn.BatchNorm2d keeps them (momentum, unbiased variance)
+            cnt = xs.numel() // xs.shape[1]
+            self.running_mean.mul_(1.0 - self.momentum).add_(mean, alpha=self.momentum)
+            self.running_var.mul_(1.0 - self.momentum).add_(var * (cnt / (cnt - 1.0)), alpha=self.momentum)
+            self.num_batches_tracked += 1
+        y = (x - mean.view(1, -1, 1, 1)) * torch.rsqrt(var.view(1, -1, 1, 1) + self.eps)
+        return y * self.weight.view(1, -1, 1, 1) + self.bias.view(1, -1, 1, 1)
+
+
 def _conv_bn_act(cin, cout):
     # model.py:20-31: conv3x3 (no bias) + BN + LeakyReLU; indices 0/1/2 give the key names
-    return nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1, bias=False), nn.BatchNorm2d(cout), nn.LeakyReLU(LEAK))
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1, bias=False), _BatchNorm2d(cout), nn.LeakyReLU(LEAK))
 
 
 class _Residual(nn.Module):
@@ -45,8 +69,8 @@ class _Residual(nn.Module):
         super().__init__()
         self.conv1 = nn.Conv2d(f, f, 3, padding=1, bias=False)
         self.conv2 = nn.Conv2d(f, f, 3, padding=1, bias=False)
-        self.batch_norm1 = nn.BatchNorm2d(f)
-        self.batch_norm2 = nn.BatchNorm2d(f)
+        self.batch_norm1 = _BatchNorm2d(f)
+        self.batch_norm2 = _BatchNorm2d(f)
 
     def forward(self, x):
         y = F.leaky_relu(self.batch_norm1(self.conv1(x)), LEAK)
@@ -60,7 +84,7 @@ class _ValueHead(nn.Module):
     def __init__(self, f, n_fc):
         super().__init__()
         self.conv1 = nn.Conv2d(f, 1, 1)
-        self.batch_norm = nn.BatchNorm2d(1)
+        self.batch_norm = _BatchNorm2d(1)
         self.fcN = nn.Sequential(*[nn.Linear(AREA, AREA) for _ in range(n_fc)])
         self.fc1 = nn.Linear(AREA, 1)
         self.w1 = nn.Parameter(torch.tensor(1.0), requires_grad=False)
@@ -79,7 +103,7 @@ class _PolicyHead(nn.Module):
     def __init__(self, f):
         super().__init__()
         self.conv1 = nn.Conv2d(f, 2, 1)
-        self.batch_norm = nn.BatchNorm2d(2)
+        self.batch_norm = _BatchNorm2d(2)
         self.fc1 = nn.Linear(2 * AREA, WIDTH)
 
     def forward(self, x):

@@ -53,7 +53,7 @@ class Trainer:
     the reference's rule (cuda:0 when use_gpu and a GPU is there, model.py:143-147) -- a multi-rank caller
     passes its own GPU."""
 
-    def __init__(self, config: ModelConfig = None, file_name: str = None, device=None):
+    def __init__(self, config: ModelConfig = None, file_name: str = None, device=None, pad_ragged_batches=None):
         self.config = config or ModelConfig()
         self.net = PolicyValueNet(self.config.net_config)
         if device is not None:
@@ -61,6 +61,8 @@ class Trainer:
         else:
             self.device = torch.device("cuda:0" if self.config.use_gpu and torch.cuda.is_available() else "cpu")
         self.net.to(self.device)
+        # the ragged last batch of an epoch is padded to the full batch size (see net._BatchNorm2d); on by default on a GPU
+        self.pad_ragged_batches = (self.device.type == "cuda") if pad_ragged_batches is None else bool(pad_ragged_batches)
         self.optimiser = torch.optim.SGD(self.net.parameters(), lr=self.config.initial_lr,
                                          momentum=self.config.momentum, weight_decay=self.config.weight_decay)
         self.scheduler = MultiStepLR(self.optimiser, milestones=self.config.milestones, gamma=self.config.gamma)
@@ -85,9 +87,17 @@ class Trainer:
             perm = dataloader_permutation(n, generator).to(self.device)
             for i in range(0, n, self.config.batch_size):
                 idx = perm[i:i + self.config.batch_size]
+                k = int(idx.shape[0])
+                pad = self.pad_ragged_batches and k < self.config.batch_size and n > self.config.batch_size and k > 1
+                if pad:   # DataLoader's drop_last=False batch (model.py:208-212), at the full batch's shape
+                    idx = torch.cat([idx, idx[:1].expand(self.config.batch_size - k)])
+                    self._set_valid_rows(k)
                 b, v, p = boards[idx], values[idx], priors[idx]
                 self.optimiser.zero_grad()
                 xv, xp = self.net(b)
+                if pad:
+                    xv, xp, v, p = xv[:k], xp[:k], v[:k], p[:k]
+                    self._set_valid_rows(None)
                 loss = self.value_loss(xv, v) + self.prior_loss(xp, p)   # model.py:221-225
                 loss.backward()
                 self.optimiser.step()
@@ -95,6 +105,12 @@ class Trainer:
         self.scheduler.step()       # once per generation (model.py:239)
         self.net.eval()
         return last
+
+    def _set_valid_rows(self, k):
+        from .net import _BatchNorm2d
+        for m in self.net.modules():
+            if isinstance(m, _BatchNorm2d):
+                m.valid_rows = k
 
     def save(self, folder_path):    # model.py:242-250
         os.makedirs(folder_path, exist_ok=True)

@@ -79,3 +79,29 @@ def test_dataloader_permutation_consumes_rng_like_dataloader():
         perm = dataloader_permutation(37)
         got += [x[perm[i:i + 8]].tolist() for i in range(0, 37, 8)]
     assert got == want
+
+
+def test_padded_ragged_batch_trains_exactly_like_the_ragged_batch():
+    """The trainer's GPU default pads the ragged last batch of an epoch to the full batch size (so every convolution
+    keeps the one shape MIOpen has kernels for) and takes the batch-norm statistics from the real rows only.  That must
+    be the same training step: identical weights, running statistics and loss as the unpadded ragged batch."""
+    import copy
+    import torch
+    from connect4_amd.training import ModelConfig, Trainer
+    torch.manual_seed(3)
+    n = 2 * 64 + 23                       # two full batches and a ragged one of 23 rows
+    boards = (torch.rand(n, 3, 6, 7) > 0.7).float()
+    values = torch.rand(n)
+    priors = torch.softmax(torch.rand(n, 7), 1)
+    cfg = ModelConfig(batch_size=64, n_training_epochs=2, use_gpu=False)
+    a = Trainer(cfg, device="cpu", pad_ragged_batches=False)
+    b = Trainer(cfg, device="cpu", pad_ragged_batches=True)
+    b.net.load_state_dict(copy.deepcopy(a.net.state_dict()))
+    ga, gb = torch.Generator().manual_seed(11), torch.Generator().manual_seed(11)
+    la = a.train(boards, values, priors, generator=ga)
+    lb = b.train(boards, values, priors, generator=gb)
+    assert abs(la - lb) < 1e-6
+    sa, sb = a.net.state_dict(), b.net.state_dict()
+    for k in sa:
+        assert torch.allclose(sa[k].double(), sb[k].double(), atol=2e-6, rtol=1e-5), k
+    assert int(sa["body.0.1.num_batches_tracked"]) == int(sb["body.0.1.num_batches_tracked"]) == 6

@@ -36,10 +36,9 @@ def main():
     out = a.out or tempfile.mkdtemp(prefix="c4gen_")
     # warm the runtime (first launches, allocator) on a toy generation that is not timed
     run_generation(tr, MCTSConfig.self_play(32), n_games=64, save_dir=None, gen=0, n_slots=64)
-    # ... and MIOpen's one-time kernel search for the training shape (batch 4096 forward/backward: ~15 s in a
-    # fresh process, cached afterwards) on a throw-away trainer.  The ragged LAST batch of the timed generation is
-    # still a new shape and pays its own search (6-9 s measured; MIOPEN_FIND_MODE=FAST avoids it but picks
-    # kernels that run the whole training 5x slower -- not adopted); it is reported inside train_and_checkpoint_s.
+    # ... and MIOpen's one-time kernel build for the training shape (batch 4096 forward/backward: ~15 s in a fresh
+    # process, cached afterwards) on a throw-away trainer.  The ragged LAST batch of an epoch is no new shape: the
+    # trainer pads it to the full batch and takes the batch-norm statistics from the real rows (net._BatchNorm2d).
     warm = Trainer(ModelConfig(n_training_epochs=1), device="cuda:0")
     wn = 2 * 4096
     warm.train((torch.rand(wn, 3, 6, 7, device="cuda") > 0.7).float(), torch.rand(wn, device="cuda"),

@@ -702,7 +702,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
     const unsigned long long wave_mask0 = WAVE_SYNC ? __builtin_amdgcn_ballot_w64(true) : 0ull;
     bool waiting = false;   // SPLIT: the leaf is with the network waves
 #if C4_SPLIT_PHASES
-    unsigned long long ph_t0 = 0, ph_iter = 0, ph_wait = 0, ph_apply = 0, ph_levels = 0, ph_n = 0, ph_ta = 0;
+    unsigned long long ph_t0 = 0, ph_iter = 0, ph_wait = 0, ph_apply = 0, ph_levels = 0, ph_n = 0, ph_ta = 0, ph_probe = 0, ph_term = 0;
     bool ph_was_waiting = false;
 #endif
     for (;;) {
@@ -1159,6 +1159,9 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
         stamp(3);
         const uint32_t lst = info_status(cinfo);
         if (lst >= ST_XWIN) {
+#if C4_SPLIT_PHASES
+            const unsigned long long ph_tt = __builtin_amdgcn_s_memtime();
+#endif
             // mcts.py:125-128,134 + :164-168: terminal leaf, exact result, no evaluator
             const double value = 0.5 * (double)(lst - ST_XWIN);
             lds_fence();   // s_path written by lane 0
@@ -1175,6 +1178,9 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             st.sims += 1;
             st.terminal_sims += 1;
             group_fence();
+#if C4_SPLIT_PHASES
+            ph_term += __builtin_amdgcn_s_memtime() - ph_tt;
+#endif
             continue;
         }
         // fresh non-terminal leaf: needs the evaluator (mcts.py:130)
@@ -1195,7 +1201,15 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
         if (EVAL == C4_EVAL_EXTERNAL_F32 && d.cache) {   // evaluators.py:19-20 position_table.get
             float cv, cp;
             st.cache_probes += 1;
+#if C4_SPLIT_PHASES
+            const unsigned long long ph_tp = __builtin_amdgcn_s_memtime();
+            const bool ph_hit = cache_probe(d, b0, b1, lane, cv, cp);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ph_probe += __builtin_amdgcn_s_memtime() - ph_tp;
+            if (ph_hit) {
+#else
             if (cache_probe(d, b0, b1, lane, cv, cp)) {   // a hit is applied in place, like a terminal leaf
+#endif
                 st.cache_hits += 1;
                 ev_value = (double)cv;
                 ev_prior = (double)cp;
@@ -1255,7 +1269,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             sm->gid = gid;
             sm->flags = SlotMem::pack(state, has_leaf, need_root);
 #if C4_SPLIT_PHASES
-            if (SPLIT && d.has_stamps && g < 256) { unsigned long long *o = d.cold->stamps + (size_t)g * 8; o[0] = ph_iter; o[1] = ph_wait; o[2] = ph_apply; o[3] = ph_levels; o[4] = ph_n; }
+            if (SPLIT && d.has_stamps && g < 256) { unsigned long long *o = d.cold->stamps + (size_t)g * 8; o[0] = ph_iter; o[1] = ph_wait; o[2] = ph_apply; o[3] = ph_levels; o[4] = ph_n; o[5] = ph_probe; o[6] = ph_term; }
 #endif
             const uint32_t *sv = (const uint32_t *)&st;   // counters: per workgroup, flushed once per launch
 #pragma unroll

@@ -30,8 +30,9 @@ a = a[a[:, 4] > 0]
 it, wait, app, lev, n = a[:, 0], a[:, 1], a[:, 2], a[:, 3], a[:, 4]
 sims = (s1["simulations"] - s0["simulations"]) / slots
 print("slots sampled %d; per slot and launch: %.0f walking iterations, %.0f simulations (all slots)" % (len(a), n.mean(), sims))
-print("cycles per walking iteration: %.0f  (apply %.0f, level loop %.0f, rest %.0f)" %
-      ((it / n).mean(), (app / n).mean(), (lev / n).mean(), ((it - app - lev) / n).mean()))
+probe, term = a[:, 5], a[:, 6]
+print("cycles per walking iteration: %.0f  (apply %.0f, level loop %.0f, cache probe %.0f, terminal backup %.0f, rest %.0f)" %
+      ((it / n).mean(), (app / n).mean(), (lev / n).mean(), (probe / n).mean(), (term / n).mean(), ((it - app - lev - probe - term) / n).mean()))
 print("share of the launch a slot spends waiting for the network: %.3f   (walking %.3f)" %
       ((wait / (it + wait)).mean(), (it / (it + wait)).mean()))
 print("hit rate %.3f, mean leaf depth %.2f" % ((s1["eval_cache_hits"] - s0["eval_cache_hits"]) / max(1, s1["eval_cache_probes"] - s0["eval_cache_probes"]),

@@ -103,6 +103,7 @@ SIGNATURES = {
     "c4_eval_cache_lookup": (C.c_int, [C.c_void_p, _u64p, _u64p, C.c_int32, _f32p, _f32p, _i32p]),
     "c4_debug_root_noise": (C.c_int, [C.c_int, C.c_uint64, C.c_double, _i64p, _i32p, _i32p, C.c_int32, _f64p, _f64p]),
     "c4_debug_sample_move": (C.c_int, [C.c_int, C.c_uint64, _i64p, _i32p, _f64p, _i32p, _f64p, C.c_int32, _f64p, _i32p]),
+    "c4_debug_div_mismatches": (C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_int64, _i64p]),
     "c4_board_make_move": (C.c_int, [C.c_int, _u64p, _u64p, _i32p, C.c_int32, _u64p, _u64p, _i32p]),
     "c4_board_wins": (C.c_int, [C.c_int, _u64p, C.c_int32, _i32p]),
     "c4_board_valid_mask": (C.c_int, [C.c_int, _u64p, _u64p, C.c_int32, _i32p]),

@@ -56,6 +56,9 @@
 #ifndef C4_SPLIT_PHASES
 #define C4_SPLIT_PHASES 0       // diagnostic build only: per-slot cycles per phase of the split kernel's tree walk (tools/split_stamps.py)
 #endif
+#ifndef C4_DIV_NORMAL
+#define C4_DIV_NORMAL 1
+#endif
 #ifndef C4_SPLIT_PAIRS
 #define C4_SPLIT_PAIRS 1      // split kernel: a network wave takes two waiting requests into one pass (tuning aid: 0 = one position per pass)
 #endif
@@ -324,9 +327,31 @@ __device__ __forceinline__ double child_value_for(uint32_t status, uint32_t n, d
 // noise, mcts.py:180).  Otherwise it is a float32 net output and NumPy>=2 keeps
 // `pb_c * prior[c]` and `prior_score + value_score` in float32 (weak Python scalars, NEP 50).
 // Both forms are computed and one is selected: no divergent branch in the descent loop.
+// a / b for operands in the normal range, written out: the instruction sequence the compiler emits for an IEEE float64
+// division (v_rcp_f64, two Newton steps, one residual correction) without its v_div_scale / v_div_fmas / v_div_fixup
+// instructions, which change something only for denormal, infinite, NaN or huge-ratio operands (a zero numerator
+// comes out as +0 either way).  For 0 <= a < 2^32 and an integer 1 <= b < 2^32 the quotient is bit-identical to a / b
+// (#if C4_DIV_NORMAL == 0 restores the plain division for A/B runs: same games); three dependent instructions less on
+// the level loop's critical chain.
+__device__ __forceinline__ double div_normal(double a, double b)
+{
+#if C4_DIV_NORMAL
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = a * r;
+    const double rem = __builtin_fma(-b, q, a);
+    return __builtin_fma(rem, r, q);
+#else
+    return a / b;
+#endif
+}
+
 __device__ __forceinline__ double ucb_score(double A, double B, uint32_t nc, double p, double V, uint32_t pf64)
 {
-    const double pbc = A * (B / (double)(nc + 1));
+    const double pbc = A * div_normal(B, (double)(nc + 1));
     const double prior_score64 = pbc * p;
     const double s64 = prior_score64 + V;
     const float prior_score32 = (float)pbc * (float)p;
@@ -808,7 +833,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             // mcts.py:164-168 backpropagate over the ancestors (values captured during the descent)
             for (uint32_t i = lane; i < pdepth; i += GROUP) {
                 const PathEntry e = path_lds ? s_path[gl][i] : gpath[i];
-                const double nw = e.w + ev_value, nq = nw / (double)(e.n + 1);
+                const double nw = e.w + ev_value, nq = div_normal(nw, (double)(e.n + 1));
                 pool.n(e.node) = e.n + 1;
                 pool.w(e.node) = nw;
                 pool.q(e.node) = nq;
@@ -1167,7 +1192,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             lds_fence();   // s_path written by lane 0
             for (uint32_t i = lane; i <= depth; i += GROUP) {
                 const PathEntry e = s_path[gl][i];
-                const double nw = e.w + value, nq = nw / (double)(e.n + 1);
+                const double nw = e.w + value, nq = div_normal(nw, (double)(e.n + 1));
                 pool.n(e.node) = e.n + 1;
                 pool.w(e.node) = nw;
                 pool.q(e.node) = nq;
@@ -2046,6 +2071,33 @@ __global__ __launch_bounds__(64) void k_debug_noise(uint64_t seed, double alpha,
     const double nz = dirichlet_from_gamma(g, legal);
     if (idx < n && lane < 7) { raw[(size_t)i * 7 + lane] = g; dirichlet[(size_t)i * 7 + lane] = nz; }
 }
+// div_normal against the compiler's IEEE division, on the device, over the operands the engine divides:
+//   part 0: a = sqrt(N) (the score table's B of parent visit count N), b = n + 1   for 0 <= N < max_parent, 0 <= n < max_child
+//   part 1: a = a value sum (float32 evaluator answers accumulated in float64, as a backup does), b = n + 1
+__global__ void k_debug_div(int max_parent, int max_child, unsigned long long n_random, unsigned long long *mismatches)
+{
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    const unsigned long long pairs = (unsigned long long)max_parent * (unsigned long long)max_child;
+    for (unsigned long long i = tid; i < pairs; i += nthreads) {
+        const double a = sqrt((double)(i / (unsigned long long)max_child)), b = (double)(i % (unsigned long long)max_child + 1);
+        const double q0 = a / b, q1 = div_normal(a, b);
+        bad += __double_as_longlong(q0) != __double_as_longlong(q1);
+    }
+    for (unsigned long long i = tid; i < n_random; i += nthreads) {
+        uint32_t c[4] = {(uint32_t)i, (uint32_t)(i >> 32), 0x5eedu, 0xd1f1u};
+        philox4x32(c, 0x123456789abcdefULL);
+        const uint32_t n = c[0] % (uint32_t)max_child;                       // visits so far
+        // a sum of float32 values in [0, 1], the way visits add them (sometimes with draws' halves on top)
+        const float v0 = (float)(c[1] >> 8) * (1.0f / 16777216.0f), v1 = (float)(c[2] >> 8) * (1.0f / 16777216.0f);
+        const double w = (double)v0 * (double)(n / 2 + 1) + (double)v1 * (double)(n - n / 2) + ((c[3] & 1u) ? 0.5 * (double)(c[3] >> 20) : 0.0);
+        const double b = (double)(n + 1);
+        const double q0 = w / b, q1 = div_normal(w, b);
+        bad += __double_as_longlong(q0) != __double_as_longlong(q1);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 __global__ __launch_bounds__(64) void k_debug_sample(uint64_t seed, const long long *gid, const int32_t *ply, const double *child_values,
                                                      const int32_t *n_children, const double *u_in, int n, double *u_out, int32_t *choice)
 {
@@ -2745,6 +2797,23 @@ int c4_debug_sample_move(int device, uint64_t seed, const int64_t *game_id, cons
     }
     if (r == hipSuccess) r = hipMemcpy(uniform_out, du, sizeof(double) * n, hipMemcpyDeviceToHost);
     if (r == hipSuccess) r = hipMemcpy(choice_out, dc, sizeof(int32_t) * n, hipMemcpyDeviceToHost);
+    BOARD_EPILOGUE();
+}
+
+int c4_debug_div_mismatches(int device, int32_t max_parent_visits, int32_t max_child_visits, int64_t n_random, int64_t *mismatches)
+{
+    if (!mismatches || max_parent_visits <= 0 || max_child_visits <= 0 || n_random < 0) { set_err(g_err, "c4_debug_div_mismatches: bad argument"); return C4_EINVAL; }
+    const int n = 1;
+    BOARD_PROLOGUE();
+    unsigned long long *dm = sc.up<unsigned long long>(nullptr, 1, r);
+    if (r == hipSuccess) r = hipMemset(dm, 0, sizeof(unsigned long long));
+    if (r == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_div, dim3(4096), dim3(256), 0, 0, (int)max_parent_visits, (int)max_child_visits, (unsigned long long)n_random, dm);
+        r = hipGetLastError();
+    }
+    unsigned long long out = 0;
+    if (r == hipSuccess) r = hipMemcpy(&out, dm, sizeof(out), hipMemcpyDeviceToHost);
+    *mismatches = (int64_t)out;
     BOARD_EPILOGUE();
 }
 

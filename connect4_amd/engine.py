@@ -306,6 +306,13 @@ def debug_sample_move(seed, game_id, ply, child_values, n_children, uniforms=Non
     return u, ch
 
 
+def debug_div_mismatches(max_parent_visits=4096, max_child_visits=4096, n_random=1 << 26, device=0):
+    """Quotients of the engine's written-out float64 division that differ from `a / b` on the device (must be 0)."""
+    out = np.zeros(1, dtype=np.int64)
+    L.check(L.load().c4_debug_div_mismatches(device, int(max_parent_visits), int(max_child_visits), int(n_random), _ptr(out, C.c_int64)))
+    return int(out[0])
+
+
 def board_centre_value(color0, color1, device=0):
     c0, c1 = _u64(color0), _u64(color1)
     out = np.zeros(len(c0), dtype=np.float64)

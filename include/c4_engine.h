@@ -266,6 +266,13 @@ int c4_debug_sample_move(int device, uint64_t seed, const int64_t *game_id, cons
                          const double *child_values /* [n][7] */, const int32_t *n_children,
                          const double *uniforms /* may be NULL */, int32_t n, double *uniform_out, int32_t *choice_out);
 
+/* The level loop and the backups divide with an instruction sequence written out for normal-range operands (the compiler's
+ * IEEE float64 division minus its scaling / fix-up instructions; c4_engine.hip: div_normal).  This runs that sequence and the
+ * plain division on the device for every (parent visits N < max_parent_visits, child visits n < max_child_visits) pair of the
+ * PUCT score's sqrt(N) / (n + 1) (mcts.py:153-154) and for n_random value-sum / visit-count quotients of the backups
+ * (mcts.py:164-168), and returns the number of quotients whose bits differ (must be 0). */
+int c4_debug_div_mismatches(int device, int32_t max_parent_visits, int32_t max_child_visits, int64_t n_random, int64_t *mismatches);
+
 /* -- pure board functions, executed by the device code (bit-exact parity tests) ------------- */
 /* board.py:160-170 make_move + result */
 int c4_board_make_move(int device, const uint64_t *color0, const uint64_t *color1, const int32_t *col,

@@ -261,3 +261,11 @@ def test_non_finite_evaluator_answers_are_contained():
     assert st["bad_evals"] > 0 and st["simulations"] == 4 * 60
     for r in roots:
         assert r.state == 2 and 0 <= r.move < 7 and r.root_visits == 61
+
+
+def test_written_out_division_is_the_ieee_division():
+    """The PUCT score's sqrt(N) / (n + 1) and the backups' W / N run a float64 division written out for normal-range
+    operands (no v_div_scale / v_div_fmas / v_div_fixup).  On the device, for every parent / child visit count up to
+    32768 x 4096 and 2^27 random value sums, its quotient must have the bits of `a / b`."""
+    from connect4_amd.engine import debug_div_mismatches
+    assert debug_div_mismatches(32768, 4096, 1 << 27) == 0

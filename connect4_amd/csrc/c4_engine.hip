@@ -59,6 +59,9 @@
 #ifndef C4_DIV_NORMAL
 #define C4_DIV_NORMAL 1
 #endif
+#ifndef C4_SCORE_ALL
+#define C4_SCORE_ALL 1          // level loop: all eight lanes score, a select instead of a branch around the division (+1.6 %)
+#endif
 #ifndef C4_SPLIT_PAIRS
 #define C4_SPLIT_PAIRS 1      // split kernel: a network wave takes two waiting requests into one pass (tuning aid: 0 = one position per pass)
 #endif
@@ -1070,7 +1073,14 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                 lvl_t0 = t1;
             }
             const double V = child_value_for(info_status(inf), n, q, age & 1);
+#if C4_SCORE_ALL
+            // all eight lanes score (the lanes beyond the node's children hold records nobody reads otherwise): a select
+            // instead of a branch around the division
+            const double sc = ucb_score(A, B, act ? n : 0u, p, V, pf64);
+            const double s = act ? sc : -std::numeric_limits<double>::infinity();
+#else
             const double s = act ? ucb_score(A, B, n, p, V, pf64) : -std::numeric_limits<double>::infinity();
+#endif
             Pick best{s, act ? lane : -1, n, inf, w};
             group_pick(best);                                   // mcts.py:141-142 max((score, child))
             // ---- next level's request

@@ -238,6 +238,39 @@ def test_split_kernel_edge_cases_play_the_same_games(monkeypatch, cache_bits):
     net.close()
 
 
+@pytest.mark.parametrize("kind", ["f32x3", "64f"])
+def test_split_kernel_other_nets_play_the_same_games(monkeypatch, kind):
+    """The reference-precision net and the 64-filter net run the split kernel with two tree waves of eight slots and six
+    network waves (c4_selfplay_split_kernel<16, MODE, 2>): same seed => the games of the wave-autonomous kernel, id by
+    id, and -- for the reference-precision net -- of the separate kernels (c4_step + c4_net_forward)."""
+    from connect4_amd.config import MCTSConfig
+    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.net import NetConfig, random_init_state_dict
+    from connect4_amd.selfplay import SelfPlay
+    if kind == "64f":
+        net = FusedNet(random_init_state_dict(NetConfig(filters=64, n_fc_layers=6, n_residuals=2), seed=2))
+    else:
+        net = FusedNet(random_init_state_dict(seed=0), precision="f32x3")
+    cfg = MCTSConfig.self_play(32)
+    out = []
+    for mode, fused in (("wave", False), ("wave", True), ("split", True)):
+        monkeypatch.setenv("C4_FUSED_MODE", mode)
+        sp = SelfPlay(net, 40, cfg, seed=21, games_target=48, record_capacity_games=64, use_graph=False,
+                      fused_loop=fused, steps_per_launch=8, max_inner_iters=3)
+        for _ in range(2000):
+            sp.run_steps(32)
+            if sp.stats()["active_slots"] == 0:
+                break
+        games = sorted(sp.drain(), key=lambda g: g.game_id)
+        st = sp.stats()
+        sp.close()
+        assert len(games) == 48 and st["bad_evals"] == 0
+        out.append(([(g.game_id, g.moves, g.result.value, g.values, [list(p) for p in g.priors]) for g in games],
+                    {k: st[k] for k in ("simulations", "expansions", "moves", "games_finished", "terminal_sims", "leaf_evals")}))
+    assert out[0] == out[1] == out[2]
+    net.close()
+
+
 def test_mini_generation_selfplay_train_reload(tmp_path):
     """BASELINE configs[4] flow at toy size on one GPU: fused self-play -> data.pth -> train step ->
     checkpoint -> the next generation's self-play runs on the updated weights."""

@@ -2,6 +2,7 @@
 // constants, the weight view NetDev, and net_forward_block(), the per-workgroup forward used by both
 // the standalone kernel (c4_net.hip) and the fused self-play kernel (c4_engine.hip).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -615,9 +616,12 @@ __device__ __forceinline__ void net_forward_wave16n(const NetDev &nd, _Float16 *
     }
     stamp(1);
     // ------------------------------------------------------------------ residual tower
-    for (int L = 0; L < n_layers; ++L) {
-        const bool second = L & 1;
-        const int so = second ? PLANE16 : 0, dofs = second ? 0 : PLANE16;   // source / destination plane inside a position's pair
+    // one conv layer.  `second` is a compile-time constant (the block's second conv: pong -> ping, plus the block input), so
+    // the plane offsets of all operand reads and stores are instruction immediates (+1.9 % at 8192 games; ready addresses
+    // for the 27 operand fragments on top of that: nothing, and the kernel reaches the 256-VGPR limit)
+    auto layer = [&](auto second_tag, const int L) {
+        constexpr bool second = decltype(second_tag)::value;
+        constexpr int so = second ? PLANE16 : 0, dofs = second ? 0 : PLANE16;   // source / destination plane inside a position's pair
         floatx4 acc[NP][RT16][2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
@@ -681,6 +685,10 @@ __device__ __forceinline__ void net_forward_wave16n(const NetDev &nd, _Float16 *
                 for (int ct = 0; ct < 2; ++ct) store16(acc[i][rt][ct], P0(i) + dofs, rbase[rt] + 16 * ct + 4 * g, real[rt]);
         if (L == 2) stamp(14);
         if (L < 6) stamp(2 + L);
+    };
+    for (int blk = 0; blk < nd.n_res; ++blk) {
+        layer(std::false_type{}, 2 * blk);
+        layer(std::true_type{}, 2 * blk + 1);
     }
     stamp(8);
     // tower output is in p0 (n_layers is even)
@@ -880,8 +888,9 @@ __device__ __forceinline__ void net_forward_wave16p(const NetDev &nd, _Float16 *
     }
     stamp(1);
     // ------------------------------------------------------------------ residual tower
-    for (int L = 0; L < n_layers; ++L) {
-        const bool second = L & 1;
+    // one conv layer; `second` is a compile-time constant, so the plane offsets of all operand reads and stores are immediates
+    auto layer = [&](auto second_tag, const int L) {
+        constexpr bool second = decltype(second_tag)::value;
         const _Float16 *sh = second ? p1h : p0h, *sl = second ? p1l : p0l;
         _Float16 *dh = second ? p0h : p1h, *dl = second ? p0l : p1l;
         floatx4 ah[RT16][2], al[RT16][2];
@@ -946,6 +955,10 @@ __device__ __forceinline__ void net_forward_wave16p(const NetDev &nd, _Float16 *
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) store16p(ah[rt][ct], al[rt][ct], dh, dl, rbase[rt] + 16 * ct + 4 * g, real[rt]);
         if (L < 6) stamp(2 + L);
+    };
+    for (int blk = 0; blk < nd.n_res; ++blk) {
+        layer(std::false_type{}, 2 * blk);
+        layer(std::true_type{}, 2 * blk + 1);
     }
     stamp(8);
     // ------------------------------------------------------------------ 1x1 head convs
@@ -1113,8 +1126,9 @@ __device__ __forceinline__ void net_forward_wave16w(const NetDev &nd, _Float16 *
     }
     stamp(1);
     // ------------------------------------------------------------------ residual tower
-    for (int L = 0; L < n_layers; ++L) {
-        const bool second = L & 1;
+    // one conv layer; `second` is a compile-time constant, so the plane offsets of all operand reads and stores are immediates
+    auto layer = [&](auto second_tag, const int L) {
+        constexpr bool second = decltype(second_tag)::value;
         const _Float16 *src = second ? p1 : p0;
         _Float16 *dst = second ? p0 : p1;
         floatx4 acc[RT16][CT];
@@ -1170,6 +1184,10 @@ __device__ __forceinline__ void net_forward_wave16w(const NetDev &nd, _Float16 *
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) store16(acc[rt][ct], dst, rbase[rt] + 16 * ct + 4 * g, real[rt]);
         if (L < 6) stamp(2 + L);
+    };
+    for (int blk = 0; blk < nd.n_res; ++blk) {
+        layer(std::false_type{}, 2 * blk);
+        layer(std::true_type{}, 2 * blk + 1);
     }
     stamp(8);
     // tower output is in p0 (n_layers is even)

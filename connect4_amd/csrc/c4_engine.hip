@@ -2517,10 +2517,10 @@ int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *prior
             e->d_uploaded = e->d;
         }
         const dim3 g32((e->d.G + 31) / 32), g16((e->d.G + 15) / 16), blk(c4net::NTHREADS);
-        // tree waves of the split kernel: 4 (one per SIMD) for the 32-filter fp16 net; the slower forwards (reference precision,
-        // 64 filters) need more network waves: 2 tree waves of 8 slots and 6 network waves at 16 slots per CU (measured:
-        // f32x3 203 vs 184 M expansions/s, 64 filters 72 vs 62 M)
-        const int tw = e->split_tw ? e->split_tw : (nd.mode == c4net::NETMODE_F32_F16 ? 4 : 2);
+        // tree waves of the split kernel: 4 (one per SIMD) for the 32-filter nets (f32x3: 230 M expansions/s against 222 M with
+        // 2 tree waves); the 64-filter forward is slow enough to want more network waves: 2 tree waves of 8 slots and 6
+        // network waves at 16 slots per CU (111 against 104 M)
+        const int tw = e->split_tw ? e->split_tw : (nd.mode == c4net::NETMODE_F64 ? 2 : 4);
 #define C4_LAUNCH_SPLIT(TSV, MODE, TWV) hipLaunchKernelGGL((c4_selfplay_split_kernel<TSV, MODE, TWV>), (TSV == 32 ? g32 : g16), blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps)
 #define C4_LAUNCH_WAVE(MODE)                                                                                                       \
     do {                                                                                                                           \

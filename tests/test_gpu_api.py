@@ -240,9 +240,9 @@ def test_split_kernel_edge_cases_play_the_same_games(monkeypatch, cache_bits):
 
 @pytest.mark.parametrize("kind", ["f32x3", "64f"])
 def test_split_kernel_other_nets_play_the_same_games(monkeypatch, kind):
-    """The reference-precision net and the 64-filter net run the split kernel with two tree waves of eight slots and six
-    network waves (c4_selfplay_split_kernel<16, MODE, 2>): same seed => the games of the wave-autonomous kernel, id by
-    id, and -- for the reference-precision net -- of the separate kernels (c4_step + c4_net_forward)."""
+    """The reference-precision net (net_forward_wave16p in the network waves) and the 64-filter net (net_forward_wave16w;
+    two tree waves of eight slots and six network waves, c4_selfplay_split_kernel<16, MODE, 2>): same seed => the games
+    of the wave-autonomous kernel and of the separate kernels (c4_step + c4_net_forward), id by id."""
     from connect4_amd.config import MCTSConfig
     from connect4_amd.fused_net import FusedNet
     from connect4_amd.net import NetConfig, random_init_state_dict

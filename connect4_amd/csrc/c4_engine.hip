@@ -247,6 +247,17 @@ __device__ __forceinline__ uint32_t gshfl(uint32_t v, int src) { return (uint32_
 // LDS-only variant: lane 0 wrote the path stack, other lanes of the same wave read it next.  LDS
 // operations of a wave execute in order; this only has to stop the compiler and drain lgkmcnt.
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Words in LDS that waves of a workgroup exchange (request states, answers).  The pointers reach the device functions
+// as generic pointers, and a volatile access through a generic pointer is a FLAT instruction with system-scope cache
+// bits -- the wave then waits for vmcnt(0) AND lgkmcnt(0), i.e. for every store it has in flight to global memory.
+// An explicit LDS address-space access is a ds_read / ds_write that waits for the LDS queue only.
+typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32_t;
+typedef __attribute__((address_space(3))) volatile float lds_vf32_t;
+typedef __attribute__((address_space(3))) volatile uint64_t lds_vu64_t;
+__device__ __forceinline__ uint32_t lds_ld(const uint32_t *p) { return *(lds_vu32_t *)p; }
+__device__ __forceinline__ void lds_st(uint32_t *p, uint32_t v) { *(lds_vu32_t *)p = v; }
+__device__ __forceinline__ float lds_ldf(const float *p) { return *(lds_vf32_t *)p; }
+__device__ __forceinline__ void lds_st64(uint64_t *p, uint64_t v) { *(lds_vu64_t *)p = v; }
 
 __device__ __forceinline__ void group_fence()
 {
@@ -688,8 +699,8 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
     bool path_lds = (EVAL == C4_EVAL_CENTRE) || PATH_KEPT;
     bool fresh_eval = false;                    // the answer came from the evaluator: remember it
     if (SPLIT && pend >= 0) {
-        if (*(volatile uint32_t *)req != REQ_ANSWERED) return;   // its leaf is still with the network waves
-        if (lane == 0) *(volatile uint32_t *)req = REQ_IDLE;
+        if (lds_ld(req) != REQ_ANSWERED) return;   // its leaf is still with the network waves
+        if (lane == 0) lds_st(req, REQ_IDLE);
     }
     if (pend >= 0) {
         leaf0 = LDS_STATE ? sm->leaf0 : d.leaf_c0[g];
@@ -741,10 +752,10 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             if (__builtin_amdgcn_ballot_w64(!waiting) == 0) __builtin_amdgcn_s_sleep(4);   // nobody in this wave can walk
             if (waiting) {
                 if ((long long)(__builtin_amdgcn_s_memtime() - deadline) > 0) { has_leaf = 1; break; }
-                if (*(volatile uint32_t *)req != REQ_ANSWERED) continue;
-                ev_value = (double)((const volatile float *)values_in)[ai];
-                ev_prior = lane < 7 ? (double)((const volatile float *)priors_in)[(size_t)ai * 7 + lane] : 0.0;
-                if (lane == 0) *(volatile uint32_t *)req = REQ_IDLE;
+                if (lds_ld(req) != REQ_ANSWERED) continue;
+                ev_value = (double)lds_ldf((const float *)values_in + ai);
+                ev_prior = lane < 7 ? (double)lds_ldf((const float *)priors_in + (size_t)ai * 7 + lane) : 0.0;
+                if (lane == 0) lds_st(req, REQ_IDLE);
                 waiting = false;
                 apply_now = true;
                 fresh_eval = d.cache != nullptr;
@@ -886,10 +897,9 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             }
             if (SPLIT) {   // hand the leaf to the network waves now: the other slots of this wave walk on
                 if (lane == 0) {
-                    sm->leaf0 = leaf0;
-                    sm->leaf1 = leaf1;
-                    lds_fence();
-                    *(volatile uint32_t *)req = REQ_POSTED;
+                    lds_st64(&sm->leaf0, leaf0);
+                    lds_st64(&sm->leaf1, leaf1);
+                    lds_st(req, REQ_POSTED);   // LDS executes a wave's accesses in order: the board is there before the word says so
                 }
                 waiting = true;
                 continue;
@@ -1257,10 +1267,9 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             for (uint32_t i = lane; i < depth; i += GROUP) gpath[i] = s_path[gl][i];
         if (SPLIT) {   // hand the leaf to the network waves now: the other slots of this wave walk on
             if (lane == 0) {
-                sm->leaf0 = leaf0;
-                sm->leaf1 = leaf1;
-                lds_fence();
-                *(volatile uint32_t *)req = REQ_POSTED;
+                lds_st64(&sm->leaf0, leaf0);
+                lds_st64(&sm->leaf1, leaf1);
+                lds_st(req, REQ_POSTED);   // LDS executes a wave's accesses in order: the board is there before the word says so
             }
             waiting = true;
             continue;
@@ -1715,7 +1724,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
             bool runnable = false;
             if (grp < SPW && sl < TS) {
                 const uint32_t fl = smem[sl].flags;
-                runnable = (fl & 0xffu) == SLOT_ACTIVE && (((fl >> 8) & 0xffu) == 0 || *(volatile uint32_t *)&s_req[sl] == REQ_ANSWERED);
+                runnable = (fl & 0xffu) == SLOT_ACTIVE && (((fl >> 8) & 0xffu) == 0 || lds_ld(&s_req[sl]) == REQ_ANSWERED);
             }
             if (__builtin_amdgcn_ballot_w64(runnable) == 0) {   // every slot waits for the network (or is parked)
                 __builtin_amdgcn_s_sleep(8);
@@ -1733,8 +1742,8 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
         const int nw = role_idx;   // network wave index: its planes
         const int lw = threadIdx.x & 63;
         for (;;) {
-            const uint32_t done = *(volatile uint32_t *)&s_tree_done;   // read BEFORE the requests: no post can follow a full count
-            const uint32_t r = lw < TS ? *(volatile uint32_t *)&s_req[lw] : REQ_IDLE;
+            const uint32_t done = lds_ld(&s_tree_done);   // read BEFORE the requests: no post can follow a full count
+            const uint32_t r = lw < TS ? lds_ld(&s_req[lw]) : REQ_IDLE;
             unsigned long long m = __builtin_amdgcn_ballot_w64(r == REQ_POSTED);
             if (m == 0) {
                 if (done == (uint32_t)TW) break;
@@ -1775,8 +1784,8 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
             const uint64_t p0 = smem[c].leaf0, p1 = smem[c].leaf1;
             const float ppr = (SPECULATE && lw < 7) ? s_pri[c * 7 + lw] : -1.0f;
             if (lw == 0) {
-                *(volatile uint32_t *)&s_req[c] = REQ_ANSWERED;
-                if (PAIRS && c2 >= 0) *(volatile uint32_t *)&s_req[c2] = REQ_ANSWERED;
+                lds_st(&s_req[c], REQ_ANSWERED);
+                if (PAIRS && c2 >= 0) lds_st(&s_req[c2], REQ_ANSWERED);
             }
             if (PAIRS && c2 >= 0) n_pass += 1;
             if (d.has_stamps) { t_busy += __builtin_amdgcn_s_memtime() - ta; n_pass += 1; }
@@ -1788,7 +1797,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
             // waiting, this wave evaluates that child now and puts the answer into the cache; when the search gets there
             // its probe hits instead of costing the slot a network round trip.  Tree waves do nothing for it.
             if (SPECULATE && !(PAIRS && c2 >= 0) && d.cache != nullptr) {
-                const uint32_t r2 = lw < TS ? *(volatile uint32_t *)&s_req[lw] : REQ_IDLE;
+                const uint32_t r2 = lw < TS ? lds_ld(&s_req[lw]) : REQ_IDLE;
                 if (__builtin_amdgcn_ballot_w64(r2 == REQ_POSTED) != 0) continue;   // real work first
                 uint64_t c0 = p0, c1 = p1;
                 int go_spec = 0;

@@ -511,6 +511,9 @@ __device__ __forceinline__ void store16(const floatx4 &acc, _Float16 *dst, int o
     if (real) *reinterpret_cast<half4 *>(dst + off) = o;
 }
 
+#ifndef C4_NET_STAMP_LAYER
+#define C4_NET_STAMP_LAYER 2   // diagnostic stamps 12..14 split this layer of the tower into k-loop / skip / epilogue
+#endif
 #ifndef C4_NET_BDEPTH
 #define C4_NET_BDEPTH 2   // operand ring of the tower's k-loop: reads run this many taps minus one ahead (3 and 4 measured the same)
 #endif
@@ -660,7 +663,7 @@ __device__ __forceinline__ void net_forward_wave16n(const NetDev &nd, _Float16 *
                 w[2 * t + ct] = wnext[(2 * t + ct) * 64];
             }
         }
-        if (L == 2) stamp(12);
+        if (L == C4_NET_STAMP_LAYER) stamp(12);
         if (second) {   // + block input (lives in dst): skip[cout][pixel] = sum_k I[cout][k] x[k][pixel]
 #pragma unroll
             for (int i = 0; i < NP; ++i)
@@ -676,14 +679,14 @@ __device__ __forceinline__ void net_forward_wave16n(const NetDev &nd, _Float16 *
                     }
                 }
         }
-        if (L == 2) stamp(13);
+        if (L == C4_NET_STAMP_LAYER) stamp(13);
 #pragma unroll
         for (int i = 0; i < NP; ++i)
 #pragma unroll
             for (int rt = 0; rt < RT16; ++rt)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) store16(acc[i][rt][ct], P0(i) + dofs, rbase[rt] + 16 * ct + 4 * g, real[rt]);
-        if (L == 2) stamp(14);
+        if (L == C4_NET_STAMP_LAYER) stamp(14);
         if (L < 6) stamp(2 + L);
     };
     for (int blk = 0; blk < nd.n_res; ++blk) {

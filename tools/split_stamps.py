@@ -52,5 +52,6 @@ if len(st):
     dd = st[:, 1:11] - st[:, 0:10]
     print("network pass inside the split kernel (%d waves sampled), cycles per phase (median): " % len(st) +
           " ".join("%s=%d" % (n, x) for n, x in zip(names, np.median(dd, axis=0))) + "  total=%d" % np.median(st[:, 10] - st[:, 0]))
-    print("   layer 2 split (median): k-loop=%d skip=%d epilogue=%d" %
-          (np.median(st[:, 12] - st[:, 3]), np.median(st[:, 13] - st[:, 12]), np.median(st[:, 14] - st[:, 13])))
+    sl = int(os.environ.get("C4_NET_STAMP_LAYER", "2"))   # the layer the diagnostic build splits (-DC4_NET_STAMP_LAYER=n)
+    print("   layer %d split (median): k-loop=%d skip=%d epilogue=%d" %
+          (sl, np.median(st[:, 12] - st[:, 1 + sl]), np.median(st[:, 13] - st[:, 12]), np.median(st[:, 14] - st[:, 13])))

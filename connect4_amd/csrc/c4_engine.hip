@@ -62,6 +62,10 @@
 #ifndef C4_SCORE_ALL
 #define C4_SCORE_ALL 1          // level loop: all eight lanes score, a select instead of a branch around the division (+1.6 %)
 #endif
+#ifndef C4_PATH_ALL_LANES
+#define C4_PATH_ALL_LANES 1      // the descent's path entries are stored by all eight lanes of the group (same words, same address): no
+                                // exec-mask region per level (+0.5 %; the same for the parent's record in the apply: nothing)
+#endif
 #ifndef C4_SPLIT_PAIRS
 #define C4_SPLIT_PAIRS 1      // split kernel: a network wave takes two waiting requests into one pass (tuning aid: 0 = one position per pass)
 #endif
@@ -1034,7 +1038,11 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             }
             b0 = root0;
             b1 = root1;
+#if C4_PATH_ALL_LANES
+            s_path[gl][0] = PathEntry{0u, cN, cW};
+#else
             if (lane == 0) s_path[gl][0] = PathEntry{0u, cN, cW};
+#endif
         }
         int age = popc64(b0 | b1);
 #if C4_SPLIT_PHASES
@@ -1114,7 +1122,11 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             }
             age += 1;
             depth += 1;
+#if C4_PATH_ALL_LANES
+            s_path[gl][depth] = PathEntry{cur, cN, cW};   // all eight lanes store the same entry: no exec-mask region in the level loop
+#else
             if (lane == 0) s_path[gl][depth] = PathEntry{cur, cN, cW};
+#endif
             r = rn;
             ab = abn;
             if (STAMPS && d.has_stamps) {

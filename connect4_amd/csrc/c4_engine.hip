@@ -66,6 +66,9 @@
 #define C4_PATH_ALL_LANES 1      // the descent's path entries are stored by all eight lanes of the group (same words, same address): no
                                 // exec-mask region per level (+0.5 %; the same for the parent's record in the apply: nothing)
 #endif
+#ifndef C4_PEEL_BACKUP
+#define C4_PEEL_BACKUP 1
+#endif
 #ifndef C4_SPLIT_PAIRS
 #define C4_SPLIT_PAIRS 1      // split kernel: a network wave takes two waiting requests into one pass (tuning aid: 0 = one position per pass)
 #endif
@@ -849,13 +852,21 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                 pool.info(pend) = pack_info(base, nchild, ST_EVALUATED, info_bit(pinfo), pf64);
             }
             // mcts.py:164-168 backpropagate over the ancestors (values captured during the descent)
-            for (uint32_t i = lane; i < pdepth; i += GROUP) {
-                const PathEntry e = path_lds ? s_path[gl][i] : gpath[i];
-                const double nw = e.w + ev_value, nq = div_normal(nw, (double)(e.n + 1));
-                pool.n(e.node) = e.n + 1;
-                pool.w(e.node) = nw;
-                pool.q(e.node) = nq;
-                if (l1_valid && i == 1) { Rec &c = s_l1[gl][e.node & 7]; c.n = e.n + 1; c.w = nw; c.q = nq; }
+            {   // (a path is rarely longer than the group is wide: the first eight entries without a loop around them)
+                auto back_up = [&](uint32_t i) {
+                    const PathEntry e = path_lds ? s_path[gl][i] : gpath[i];
+                    const double nw = e.w + ev_value, nq = div_normal(nw, (double)(e.n + 1));
+                    pool.n(e.node) = e.n + 1;
+                    pool.w(e.node) = nw;
+                    pool.q(e.node) = nq;
+                    if (l1_valid && i == 1) { Rec &c = s_l1[gl][e.node & 7]; c.n = e.n + 1; c.w = nw; c.q = nq; }
+                };
+#if C4_PEEL_BACKUP
+                if ((uint32_t)lane < pdepth) back_up((uint32_t)lane);
+                for (uint32_t i = lane + GROUP; i < pdepth; i += GROUP) back_up(i);
+#else
+                for (uint32_t i = lane; i < pdepth; i += GROUP) back_up(i);
+#endif
             }
             root_w = pdepth == 0 ? ev_value : root_w + ev_value;
             if (pdepth == 0) l1_valid = false;   // a new sibling block under the root
@@ -1222,13 +1233,21 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             // mcts.py:125-128,134 + :164-168: terminal leaf, exact result, no evaluator
             const double value = 0.5 * (double)(lst - ST_XWIN);
             lds_fence();   // s_path written by lane 0
-            for (uint32_t i = lane; i <= depth; i += GROUP) {
-                const PathEntry e = s_path[gl][i];
-                const double nw = e.w + value, nq = div_normal(nw, (double)(e.n + 1));
-                pool.n(e.node) = e.n + 1;
-                pool.w(e.node) = nw;
-                pool.q(e.node) = nq;
-                if (l1_valid && i == 1) { Rec &c = s_l1[gl][e.node & 7]; c.n = e.n + 1; c.w = nw; c.q = nq; }
+            {
+                auto back_up = [&](uint32_t i) {
+                    const PathEntry e = s_path[gl][i];
+                    const double nw = e.w + value, nq = div_normal(nw, (double)(e.n + 1));
+                    pool.n(e.node) = e.n + 1;
+                    pool.w(e.node) = nw;
+                    pool.q(e.node) = nq;
+                    if (l1_valid && i == 1) { Rec &c = s_l1[gl][e.node & 7]; c.n = e.n + 1; c.w = nw; c.q = nq; }
+                };
+#if C4_PEEL_BACKUP
+                if ((uint32_t)lane <= depth) back_up((uint32_t)lane);
+                for (uint32_t i = lane + GROUP; i <= depth; i += GROUP) back_up(i);
+#else
+                for (uint32_t i = lane; i <= depth; i += GROUP) back_up(i);
+#endif
             }
             root_w = root_w + value;
             sims += 1;

@@ -69,6 +69,9 @@
 #ifndef C4_PEEL_BACKUP
 #define C4_PEEL_BACKUP 1
 #endif
+#ifndef C4_NO_SUSPEND
+#define C4_NO_SUSPEND 1
+#endif
 #ifndef C4_SPLIT_PAIRS
 #define C4_SPLIT_PAIRS 1      // split kernel: a network wave takes two waiting requests into one pass (tuning aid: 0 = one position per pass)
 #endif
@@ -737,7 +740,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
     // shader cycles, so cheap (shallow / terminal / cached) simulations are not rationed by count and
     // every wave of a launch ends at about the same time
     const unsigned long long t_begin = (!WAVE_SYNC && d.time_budget > 0) ? __builtin_amdgcn_s_memtime() : 0;
-    bool resume = (pend == -2);
+    bool resume = !(WAVE_SYNC && C4_NO_SUSPEND) && (pend == -2);   // the wave-autonomous kernels have no level budget: no descent is ever suspended there
     // Hot subtree in LDS: once a launch has loaded the root's sibling block it stays in s_l1 for all
     // further simulations of the launch (write-through on every backup), so level 1 of every later
     // descent is an LDS read instead of an HBM round trip.
@@ -1205,7 +1208,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             d.cold->stamps[blockIdx.x * 8 + 7] = (lvl_wait << 32) | (lvl_alu & 0xffffffffu);
             d.cold->stamps[blockIdx.x * 8 + 6] = ((unsigned long long)lvl_cnt << 32) | depth;
         }
-        if (info_status(cinfo) == ST_EVALUATED) {   // level budget exhausted mid-descent: suspend
+        if (!(WAVE_SYNC && C4_NO_SUSPEND) && info_status(cinfo) == ST_EVALUATED) {   // level budget exhausted mid-descent: suspend
             lds_fence();
             for (uint32_t i = lane; i <= depth; i += GROUP) gpath[i] = s_path[gl][i];
             if (lane == 0) {

@@ -72,6 +72,9 @@
 #ifndef C4_NO_SUSPEND
 #define C4_NO_SUSPEND 1
 #endif
+#ifndef C4_NET_SANITISES
+#define C4_NET_SANITISES 1
+#endif
 #ifndef C4_SPLIT_PAIRS
 #define C4_SPLIT_PAIRS 1      // split kernel: a network wave takes two waiting requests into one pass (tuning aid: 0 = one position per pass)
 #endif
@@ -708,6 +711,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
     // own for the whole launch (no global round trip between emitting a leaf and applying its answer)
     bool path_lds = (EVAL == C4_EVAL_CENTRE) || PATH_KEPT;
     bool fresh_eval = false;                    // the answer came from the evaluator: remember it
+    bool cached_answer = false;                 // the answer came from the evaluation cache (finite by construction)
     if (SPLIT && pend >= 0) {
         if (lds_ld(req) != REQ_ANSWERED) return;   // its leaf is still with the network waves
         if (lane == 0) lds_st(req, REQ_IDLE);
@@ -777,14 +781,12 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             ph_ta = __builtin_amdgcn_s_memtime();
 #endif
             apply_now = false;
-            if (fresh_eval) {   // evaluators.py:21-24: position_table[key] = evaluate_fn(board)
-                fresh_eval = false;
-                cache_insert(d, leaf0, leaf1, lane, (float)ev_value, (float)ev_prior);
-            }
             // The reference asserts that the net never answers NaN (model.py:258-263).  A NaN here would
             // poison every comparison of the argmax, so answers are made finite first: memory safety of
-            // the walk must not depend on the evaluator (counted in stats as bad_evals).
-            {
+            // the walk must not depend on the evaluator (counted in stats as bad_evals).  Only finite answers reach the
+            // evaluation cache, so a cache hit needs no check; in the split kernel the network wave has looked at a fresh
+            // answer before it published it (sanitise_answer), and the tree waves carry no check at all.
+            if (!(SPLIT && C4_NET_SANITISES) && !cached_answer) {   // (an answer of any evaluator: the device net, a host callable, the centre heuristic)
                 const bool bad = !(ev_value >= 0.0 && ev_value <= 1.0) || !(ev_prior >= 0.0 && ev_prior <= 3.0e38);
                 if (__ballot(bad) >> (((threadIdx.x & 63) / GROUP) * GROUP) & 0xffull) {
                     if (!(ev_value >= 0.0 && ev_value <= 1.0)) ev_value = 0.5;
@@ -792,6 +794,11 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                     st.bad_evals += 1;
                 }
             }
+            if (fresh_eval) {   // evaluators.py:21-24: position_table[key] = evaluate_fn(board)
+                fresh_eval = false;
+                cache_insert(d, leaf0, leaf1, lane, (float)ev_value, (float)ev_prior);
+            }
+            cached_answer = false;
             const uint64_t occ = leaf0 | leaf1;
             const int age = popc64(occ);
             const int mask = legal_mask(occ);                    // tree.py:23 valid_moves (leaf is undecided)
@@ -910,6 +917,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                     ev_value = (double)cv;
                     ev_prior = (double)cp;
                     apply_now = true;
+                    cached_answer = true;
                     continue;
                 }
             }
@@ -1294,6 +1302,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                 ev_prior = (double)cp;
                 path_lds = true;
                 apply_now = true;
+                cached_answer = true;
                 continue;
             }
         }
@@ -1656,6 +1665,22 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
     }
 }
 
+// A network wave looks at an answer before it publishes it (the eight lanes 0..7 of the wave: value, prior[lane]): a value
+// outside [0, 1] or a prior that is not a finite non-negative number is replaced (0.5 / 0) and counted (bad_evals), as
+// tree_step's apply does it in the other kernels.
+__device__ __forceinline__ void sanitise_answer(float *s_val, float *s_pri, int row, int lw, uint32_t *wg_stats)
+{
+    if (lw < GROUP) {
+        const float v = s_val[row], p = lw < 7 ? s_pri[row * 7 + lw] : 0.0f;
+        const bool bad_v = !(v >= 0.0f && v <= 1.0f), bad_p = !(p >= 0.0f && p <= 3.0e38f);
+        if (__builtin_amdgcn_ballot_w64(bad_v || bad_p) & 0xffull) {
+            if (bad_v && lw == 0) s_val[row] = 0.5f;
+            if (bad_p && lw < 7) s_pri[row * 7 + lw] = 0.0f;
+            if (lw == 0) atomicAdd(&wg_stats[offsetof(SlotStats, bad_evals) / sizeof(uint64_t)], 1u);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // c4_selfplay_split_kernel<TS, MODE>: tree waves and network waves.
 // The wave-autonomous kernel above gives every wave 2 slots (16 of its 64 lanes walk trees) and lets it stop
@@ -1814,6 +1839,11 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
                                              (C4_FUSED_NET_STAMPS && d.has_stamps && blockIdx.x < 16) ? d.cold->stamps + 2048 + (blockIdx.x * NWAVES + nw) * 16 : nullptr);
             }
             lds_fence();   // the answer is in LDS before the request word says so
+            if (C4_NET_SANITISES) {   // see tree_step's apply: answers leave this wave finite
+                sanitise_answer(s_val, s_pri, c, lw, s_stats);
+                if (PAIRS && c2 >= 0) sanitise_answer(s_val, s_pri, c2, lw, s_stats);
+                lds_fence();
+            }
             // (speculation, below) the answered position and its priors, read before the slot may reuse its rows
             const uint64_t p0 = smem[c].leaf0, p1 = smem[c].leaf1;
             const float ppr = (SPECULATE && lw < 7) ? s_pri[c * 7 + lw] : -1.0f;
@@ -1849,6 +1879,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
                 c1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(c1 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)c1);
                 net_forward_wave1_mode<MODE>(nd, &act[nw][0], mlp, s_bias, s_tab16, c0, c1, s_val, s_pri, TS + nw);
                 lds_fence();
+                if (C4_NET_SANITISES) { sanitise_answer(s_val, s_pri, TS + nw, lw, s_stats); lds_fence(); }
                 if (lw < GROUP) cache_insert(d, c0, c1, lw, s_val[TS + nw], lw < 7 ? s_pri[(TS + nw) * 7 + lw] : 0.0f);
                 if (lw == 0) atomicAdd(&s_stats[offsetof(SlotStats, spec_evals) / sizeof(uint64_t)], 1u);
                 // (walking further down the line of highest priors -- stepping over cached positions, a second pass -- measured

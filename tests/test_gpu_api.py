@@ -271,6 +271,36 @@ def test_split_kernel_other_nets_play_the_same_games(monkeypatch, kind):
     net.close()
 
 
+@pytest.mark.parametrize("mode", ["split", "wave"])
+def test_fused_kernels_contain_a_net_that_answers_nan(monkeypatch, mode):
+    """A checkpoint with a NaN in it must not cost memory safety (the reference asserts, model.py:258-263): the fused
+    kernels replace non-finite values / priors (network waves before they publish an answer in the split kernel, the
+    apply in the others), count them, and the games complete."""
+    import torch
+    from connect4_amd.config import MCTSConfig
+    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.net import random_init_state_dict
+    from connect4_amd.selfplay import SelfPlay
+    sd = random_init_state_dict(seed=0)
+    sd["value_head.fc1.bias"] = torch.full_like(sd["value_head.fc1.bias"], float("nan"))     # every value is NaN
+    sd["policy_head.fc1.bias"][3] = float("nan")                                              # ... and one logit, so every prior
+    net = FusedNet(sd)
+    monkeypatch.setenv("C4_FUSED_MODE", mode)
+    sp = SelfPlay(net, 24, MCTSConfig.self_play(24), seed=2, games_target=24, record_capacity_games=32, use_graph=False,
+                  fused_loop=True, steps_per_launch=8)
+    for _ in range(2000):
+        sp.run_steps(32)
+        if sp.stats()["active_slots"] == 0:
+            break
+    st = sp.stats()
+    games = sp.drain()
+    sp.close()
+    net.close()
+    assert st["bad_evals"] > 0 and len(games) == 24
+    for g in games:
+        assert 7 <= len(g.moves) <= 42
+
+
 def test_mini_generation_selfplay_train_reload(tmp_path):
     """BASELINE configs[4] flow at toy size on one GPU: fused self-play -> data.pth -> train step ->
     checkpoint -> the next generation's self-play runs on the updated weights."""

@@ -75,6 +75,9 @@
 #ifndef C4_NET_SANITISES
 #define C4_NET_SANITISES 1
 #endif
+#ifndef C4_WAIT_CLOCK_LAZY
+#define C4_WAIT_CLOCK_LAZY 1
+#endif
 #ifndef C4_SPLIT_PAIRS
 #define C4_SPLIT_PAIRS 1      // split kernel: a network wave takes two waiting requests into one pass (tuning aid: 0 = one position per pass)
 #endif
@@ -763,9 +766,19 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
         if (SPLIT) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); if (ph_t0) { (ph_was_waiting ? ph_wait : ph_iter) += tn - ph_t0; ph_n += ph_was_waiting ? 0 : 1; } ph_t0 = tn; ph_was_waiting = waiting; }
 #endif
         if (SPLIT) {
+#if C4_WAIT_CLOCK_LAZY
+            // Nobody in this wave can walk (every lane still in the loop waits): sleep, and look at the clock HERE only -- while
+            // some slot walks, the walking lanes' deadline check ends their part of the call and the waiting lanes arrive here.
+            if (__builtin_amdgcn_ballot_w64(!waiting) == 0) {
+                __builtin_amdgcn_s_sleep(4);
+                if ((long long)(__builtin_amdgcn_s_memtime() - deadline) > 0) { has_leaf = 1; break; }
+            }
+            if (waiting) {
+#else
             if (__builtin_amdgcn_ballot_w64(!waiting) == 0) __builtin_amdgcn_s_sleep(4);   // nobody in this wave can walk
             if (waiting) {
                 if ((long long)(__builtin_amdgcn_s_memtime() - deadline) > 0) { has_leaf = 1; break; }
+#endif
                 if (lds_ld(req) != REQ_ANSWERED) continue;
                 ev_value = (double)lds_ldf((const float *)values_in + ai);
                 ev_prior = lane < 7 ? (double)lds_ldf((const float *)priors_in + (size_t)ai * 7 + lane) : 0.0;

@@ -49,7 +49,7 @@ def net_mflop_per_position(filters=32, residuals=3):
     return 2.0 * macs / 1e6
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 
 
 def tree_bytes_per_sim(mean_depth):
@@ -74,8 +74,10 @@ def parse_args(argv=None):
     ap.add_argument("--preroll-max-s", type=float, default=60.0)
     ap.add_argument("--net", default="fused", choices=["fused", "torch"],
                     help="fused: hand-written gfx950 MFMA kernel; torch: PyTorch-ROCm/MIOpen")
-    ap.add_argument("--net-precision", default="f16", choices=["f16", "f32x3"],
-                    help="fused net arithmetic: f16 storage / f32 accumulate, or the reference-precision split")
+    ap.add_argument("--net-precision", default="f32x3", choices=["f16", "f32x3"],
+                    help="fused net arithmetic: f32x3 = reference precision (the reference evaluates leaves in float32, model.py:252-282: "
+                         "every fp32 operand as fp16 hi + lo, three MFMAs per k-step, fp32 accumulate; reproduces the reference's visit "
+                         "counts) -- the headline; f16 = fp16 storage / fp32 accumulate, reduced precision, reported as a secondary block")
     ap.add_argument("--net-dtype", default=None, choices=["f32", "f16", "bf16"], help="torch net only (default f32)")
     ap.add_argument("--steps-per-graph", type=int, default=8)
     ap.add_argument("--max-inner", type=int, default=32, help="evaluator-free simulations a slot may run per tree call (0 = engine default)")
@@ -90,14 +92,17 @@ def parse_args(argv=None):
                     help="for rocprofv3 --pmc passes of the standalone kernels: pre-roll with the fused kernel, then run "
                          "the timed steps as separate eager launches (no HIP graph: PMC collection crashes inside graph replay)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=200, help="event-timed eager rollout steps for the secondary per-kernel rooflines")
+    ap.add_argument("--profile-steps", type=int, default=0,
+                    help="event-timed eager rollout steps of the STANDALONE kernels (c4_step_kernel, c4_net_kernel) for secondary per-kernel "
+                         "rooflines; 0 = none (the timed region launches neither of them)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction plumbing only (no GPU, gloo): what the CPU test of --gpus N runs; "
                          "the line it prints is flagged dry_run and carries no measurement")
     ap.add_argument("--precise-compare", type=int, default=1,
-                    help="1: at N=1 also time a short run of the reference-precision fused net and report its throughput")
+                    help="1: at N=1 also time a short run of the OTHER fused-net precision (f16 storage next to the f32x3 headline, "
+                         "or the reverse) and report its throughput as a secondary block")
     return ap.parse_args(argv)
 
 
@@ -293,7 +298,11 @@ def run_rank(args):
     from connect4_amd.net import NetConfig, random_init_state_dict
 
     if args.net == "fused":
-        args.net_dtype = "f16" if args.net_precision == "f16" else "f32"
+        if args.filters != 32 and args.net_precision == "f32x3":
+            args.net_precision = "f16"     # the 64-filter forward exists in fp16 storage only (declared in dtype / config)
+        # what the leaf evaluation computes in: "f32x3" = float32 operands carried as fp16 hi + lo parts, products exact,
+        # fp32 accumulation (the reference's float32, model.py:252-282); "f16" = fp16 storage, fp32 accumulation
+        args.net_dtype = args.net_precision
     elif args.net_dtype is None:
         args.net_dtype = "f32"
     sd = random_init_state_dict(NetConfig(filters=args.filters, n_residuals=args.residuals, n_fc_layers=args.fc_layers), seed=0)
@@ -392,7 +401,10 @@ def run_rank(args):
             r_depth = delta["depth_sum"] / max(1, delta["simulations"])
             tree_b = tree_bytes_per_sim(r_depth) * r_sims
             ach = tree_b / (launch_ms * 1e-3) / 1e9
+            # algorithmic network FLOPs (4.74 MFLOP per position); the f32x3 mode issues three fp16 MFMAs per algorithmic product,
+            # reported separately as mfma_issued_tflops
             mfma_tf = args.net_mflop * 1e6 * r_evals / (launch_ms * 1e-3) / 1e12
+            mfma_issue_factor = 3.0 if args.net_precision == "f32x3" else 1.0
             # PMC traffic only from a record of launches of exactly this shape
             pmc_ok = (pmc.get("kernel", "") == FUSED_KERNEL and args.slots == pmc.get("slots") and args.sims == pmc.get("sims")
                       and args.max_inner == pmc.get("max_inner") and args.quanta_per_step == pmc.get("quanta_per_launch")
@@ -408,6 +420,8 @@ def run_rank(args):
                 "sims_per_launch": r_sims, "mean_depth": r_depth, "algorithmic_bytes_per_launch": tree_b,
                 "net_positions_per_launch": r_evals, "mfma_achieved_tflops": mfma_tf,
                 "mfma_frac_of_dense_f16_peak": mfma_tf / F16_MFMA_PEAK_TF,
+                "mfma_issued_tflops": mfma_tf * mfma_issue_factor,
+                "mfma_issued_frac_of_dense_f16_peak": mfma_tf * mfma_issue_factor / F16_MFMA_PEAK_TF,
                 "note": "tree walk = dependent-load (latency) bound pointer chase, bytes = (136*D+332) per simulation (node records, "
                         "path, cache line); the network part of the same kernel is counted in mfma_achieved_tflops "
                         "(%.2f MFLOP per evaluated leaf); duration = HIP events around the timed region / launches" % args.net_mflop,
@@ -424,8 +438,11 @@ def run_rank(args):
     if hasattr(net, "close"):
         net.close()
     if rank == 0 and world == 1:
-        if args.precise_compare and fused_timed and args.net_precision == "f16":
-            out["reference_precision_mode"] = precise_compare(args, sd, out)
+        if args.precise_compare and fused_timed and args.filters == 32:
+            if args.net_precision == "f16":
+                out["reference_precision_mode"] = precise_compare(args, sd, out, "f32x3")
+            else:
+                out["f16_storage_mode"] = precise_compare(args, sd, out, "f16")
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, args.sims, args.cpu_seconds, 256)
     if rank == 0:
@@ -437,15 +454,15 @@ def run_rank(args):
     return 0
 
 
-def precise_compare(args, sd, main_line):
-    """The same workload with the reference-precision fused net (f16 hi/lo split, 3 MFMAs per k-step):
-    a short separate run, reported next to the f16 headline with its throughput cost."""
+def precise_compare(args, sd, main_line, precision):
+    """The same workload with the fused net's other arithmetic (f32x3: f16 hi/lo split, 3 MFMAs per k-step = the reference's
+    float32; f16: fp16 storage, reduced precision): a short separate run, reported next to the headline."""
     import copy
     a = copy.copy(args)
-    a.net_precision = "f32x3"
+    a.net_precision = precision
     a.steps = max(10, min(args.steps, 40))
     try:
-        sp, net = make_selfplay(a, sd, 0, 0, "f32x3")
+        sp, net = make_selfplay(a, sd, 0, 0, precision)
     except Exception as e:   # noqa: BLE001 -- report, never hide
         return {"error": "%s: %s" % (type(e).__name__, e)}
     try:
@@ -455,11 +472,15 @@ def precise_compare(args, sd, main_line):
         sp.close()
         net.close()
     v = d["expansions"] / elapsed
-    return {"net_precision": "f32x3 (fp16 hi+lo split, 3 MFMAs per k-step, fp32 accumulate; visit counts equal to the reference's fp32 net on the golden searches)",
+    label = ("f32x3 (fp16 hi+lo split, 3 MFMAs per k-step, fp32 accumulate; visit counts equal to the reference's fp32 net on the golden searches)"
+             if precision == "f32x3" else
+             "f16 (fp16 storage, fp32 accumulate: REDUCED precision against the reference's float32 net -- answers within 2e-2, visit "
+             "distributions within 0.08 total variation on the golden searches; opt-in, not the headline)")
+    return {"net_precision": label,
             "value": v, "unit": "node-expansions/s", "games_per_sec": d["games_finished"] / elapsed,
             "sims_per_sec": d["simulations"] / elapsed, "steps": a.steps, "timed_region_s": elapsed,
             "eval_cache_hit_rate": d["eval_cache_hits"] / max(1, d["eval_cache_probes"]),
-            "throughput_vs_f16": v / main_line["value"], "preroll_s": pre["preroll_s"]}
+            "throughput_vs_headline": v / main_line["value"], "preroll_s": pre["preroll_s"]}
 
 
 def profile_eager(sp, args):

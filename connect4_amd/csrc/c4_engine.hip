@@ -1643,7 +1643,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_wave_kernel(const
         } else {   // reference-precision net or 64 filters: one position per pass on 32-row tiles
             for (int i = 0; i < cnt; ++i) {
                 const int sa = pend_slot[i];
-                net_forward_wave1_mode<MODE>(nd, &act[wv][0], mlp, s_bias, s_tab16, smem[sa].leaf0, smem[sa].leaf1, s_val, s_pri, sa);
+                net_forward_wave1_mode<MODE>(nd, &act[wv][0], mlp, s_bias, s_tab16, smem[sa].leaf0, smem[sa].leaf1, s_val, s_pri, sa, nd.w0);   // (eight waves' planes fill this kernel's LDS: the pass-start fragments come from L2 here)
             }
         }
         lds_fence();   // answers (LDS) before the next tree_step reads them
@@ -1731,6 +1731,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
     __shared__ uint32_t s_stats[N_STATS];
     __shared__ __attribute__((aligned(16))) float s_bias[BIAS_LDS_FLOATS];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab16[64 * TAB16];
+    __shared__ __attribute__((aligned(16))) half8 s_w0[W0Lds<MODE>::FRAGS];  // reference-precision forward: the fragments a pass needs first
     __shared__ __attribute__((aligned(16))) PathEntry s_path[TS][MAX_DEPTH];   // every slot's descent path, for the whole launch
     __shared__ __attribute__((aligned(16))) Rec s_l1[TS][GROUP];               // every slot's root block
     __shared__ uint32_t s_req[TS];     // REQ_* of the slot's leaf
@@ -1763,6 +1764,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
     }
     for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
     stage_bias_lds(nd, s_bias);
+    if (W0Lds<MODE>::FRAGS > 1) stage_w0_lds(nd, s_w0);
     if (threadIdx.x < 64) build_tab16<MODE == NETMODE_F64 ? CS64 : CS16>(s_tab16, threadIdx.x);
     for (int i = threadIdx.x; i < TS * MAX_DEPTH; i += NTHREADS) {   // paths of leaves pending from the previous launch
         const int p = i / MAX_DEPTH, k = i - p * MAX_DEPTH;
@@ -1777,10 +1779,12 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
     __syncthreads();
     // (a placement other than two waves per SIMD -- not seen, the kernel's VGPR count allows no other -- falls back to
     // roles by wave index: a tree wave index nobody holds would leave its slots unserved)
-    const bool even = TW == 4 && s_simd[0] == 2 && s_simd[1] == 2 && s_simd[2] == 2 && s_simd[3] == 2;
+    // TW == 3 (five network waves: the reference-precision forward costs twice the fp16 one, so the network waves are the
+    // busier half there): SIMDs 0..2 carry a tree wave and a network wave, SIMD 3 two network waves.
+    const bool even = (TW == 4 || TW == 3) && s_simd[0] == 2 && s_simd[1] == 2 && s_simd[2] == 2 && s_simd[3] == 2;
     const int wv = threadIdx.x >> 6;
-    const bool is_tree = even ? rank == 0 : wv < TW;
-    const int role_idx = even ? simd : (wv < TW ? wv : wv - TW);
+    const bool is_tree = even ? (rank == 0 && simd < TW) : wv < TW;
+    const int role_idx = even ? (is_tree ? simd : (TW == 4 ? simd : (rank == 0 ? 4 : simd))) : (wv < TW ? wv : wv - TW);
     const unsigned long long t_launch = __builtin_amdgcn_s_memtime();
     const unsigned long long quantum = (unsigned long long)n_steps * (unsigned long long)(d.time_budget > 0 ? d.time_budget : 80000);
     unsigned long long t_busy = 0, n_pass = 0;   // diagnostic (C4_TREE_STAMPS=1)
@@ -1848,7 +1852,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
                 const int o[2] = {c, c2};
                 net_forward_wave16n<2>(nd, &act[nw][0], mlp, s_bias, s_tab16, a0, a1, s_val, s_pri, o);
             } else {
-                net_forward_wave1_mode<MODE>(nd, &act[nw][0], mlp, s_bias, s_tab16, smem[c].leaf0, smem[c].leaf1, s_val, s_pri, c,
+                net_forward_wave1_mode<MODE>(nd, &act[nw][0], mlp, s_bias, s_tab16, smem[c].leaf0, smem[c].leaf1, s_val, s_pri, c, s_w0,
                                              (C4_FUSED_NET_STAMPS && d.has_stamps && blockIdx.x < 16) ? d.cold->stamps + 2048 + (blockIdx.x * NWAVES + nw) * 16 : nullptr);
             }
             lds_fence();   // the answer is in LDS before the request word says so
@@ -1890,7 +1894,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
                 if (!go_spec) continue;
                 c0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(c0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
                 c1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(c1 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)c1);
-                net_forward_wave1_mode<MODE>(nd, &act[nw][0], mlp, s_bias, s_tab16, c0, c1, s_val, s_pri, TS + nw);
+                net_forward_wave1_mode<MODE>(nd, &act[nw][0], mlp, s_bias, s_tab16, c0, c1, s_val, s_pri, TS + nw, s_w0);
                 lds_fence();
                 if (C4_NET_SANITISES) { sanitise_answer(s_val, s_pri, TS + nw, lw, s_stats); lds_fence(); }
                 if (lw < GROUP) cache_insert(d, c0, c1, lw, s_val[TS + nw], lw < 7 ? s_pri[(TS + nw) * 7 + lw] : 0.0f);
@@ -1902,7 +1906,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
     }
     if (!C4_SPLIT_PHASES && d.has_stamps && blockIdx.x < 128 && (threadIdx.x & 63) == 0) {   // per wave: busy cycles (tree waves 0..3, network waves 8..11 | passes << 48)
         d.cold->stamps[blockIdx.x * 16 + (is_tree ? 0 : 8) + role_idx] = t_busy | (n_pass << 48);
-        d.cold->stamps[blockIdx.x * 16 + (is_tree ? 4 : 12) + role_idx] = (unsigned long long)simd | ((unsigned long long)even << 8);
+        if (TW == 4) d.cold->stamps[blockIdx.x * 16 + (is_tree ? 4 : 12) + role_idx] = (unsigned long long)simd | ((unsigned long long)even << 8);
     }
     __syncthreads();
     // ---- launch epilogue: LDS -> global
@@ -2612,8 +2616,9 @@ int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *prior
 #define C4_LAUNCH_WAVE(MODE)                                                                                                       \
     do {                                                                                                                           \
         if (e->fused_wave == 2) {                                                                                                  \
-            if (e->fused_slots == 32) C4_LAUNCH_SPLIT(32, MODE, 4);                                                                \
+            if (e->fused_slots == 32) C4_LAUNCH_SPLIT(32, MODE, 4);   /* (a wave holds at most 8 slots: no fewer than 4 tree waves) */ \
             else if (tw == 2) C4_LAUNCH_SPLIT(16, MODE, 2);                                                                        \
+            else if (tw == 3) C4_LAUNCH_SPLIT(16, MODE, 3);                                                                        \
             else C4_LAUNCH_SPLIT(16, MODE, 4);                                                                                     \
         } else if (e->fused_slots == 32) hipLaunchKernelGGL((c4_selfplay_wave_kernel<32, MODE>), g32, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps); \
         else hipLaunchKernelGGL((c4_selfplay_wave_kernel<16, MODE>), g16, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps); \

@@ -29,6 +29,7 @@
 // reference precision), net_forward_wave16w (64 filters).  All live in c4_net_dev.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_kernel(NetDev nd, const uint6
 template <int MODE>
 __global__ __launch_bounds__(NTHREADS) void c4_net_wave1_kernel(NetDev nd, const uint64_t *__restrict__ c0,
                                                                 const uint64_t *__restrict__ c1, int n,
-                                                                float *__restrict__ values, float *__restrict__ priors)
+                                                                float *__restrict__ values, float *__restrict__ priors, int active_waves)
 {
     __shared__ __attribute__((aligned(16))) _Float16 act[NWAVES][WaveBuf<MODE>::HALVES];
     __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_wave1_kernel(NetDev nd, const
     const int wv = threadIdx.x >> 6;
     const int p = blockIdx.x * NWAVES + wv;
     if (p >= n) return;
-    net_forward_wave1_mode<MODE>(nd, &act[wv][0], mlp, s_bias, s_tab, c0[p], c1[p], values, priors, p,
+    if (wv >= active_waves) return;                       // diagnostic (C4_NET_WAVE_ACTIVE): fewer waves per CU
+    net_forward_wave1_mode<MODE>(nd, &act[wv][0], mlp, s_bias, s_tab, c0[p], c1[p], values, priors, p, nd.w0,   /* (eight waves' planes fill this kernel's LDS: the pass-start fragments come from L2 here) */
                                  (nd.stamps && blockIdx.x == 0) ? nd.stamps + wv * 16 : nullptr);
 }
 
@@ -231,6 +233,26 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
                     if (co < 3) split(desc->head_w[co * FW + ci], head16[at], head16l[at]);
                 }
     }
+    // the 32-filter tower as one linear stream for net_forward_wave16q: [tap T = L * 9 + t][ct0 hi | ct0 lo | ct1 hi | ct1 lo][64][8]
+    std::vector<_Float16> conv16p;
+    if (FW == 32 && R > 0) {
+        conv16p.resize((size_t)2 * R * 9 * 4 * 64 * 8);
+        for (size_t T = 0; T < (size_t)2 * R * 9; ++T)
+            for (int ct = 0; ct < 2; ++ct)
+                for (int e = 0; e < 64 * 8; ++e) {
+                    conv16p[((T * 4 + 2 * ct) * 64 * 8) + e] = conv16[((T * 2 + ct) * 64 * 8) + e];
+                    conv16p[((T * 4 + 2 * ct + 1) * 64 * 8) + e] = conv16l[((T * 2 + ct) * 64 * 8) + e];
+                }
+    } else conv16p.resize(8);
+    // ... and what a pass needs first, in the order of c4net::W0_*: stem hi (4 fragments), stem lo (4), heads hi, heads lo, tower taps 0 and 1
+    std::vector<_Float16> w0v((size_t)W0_FRAGS * 64 * 8, (_Float16)0.0f);
+    if (FW == 32) {
+        std::copy(stem16.begin(), stem16.begin() + 4 * 64 * 8, w0v.begin() + (size_t)W0_STEM * 64 * 8);
+        std::copy(stem16l.begin(), stem16l.begin() + 4 * 64 * 8, w0v.begin() + (size_t)(W0_STEM + 4) * 64 * 8);
+        std::copy(head16.begin(), head16.begin() + 64 * 8, w0v.begin() + (size_t)W0_HEAD * 64 * 8);
+        std::copy(head16l.begin(), head16l.begin() + 64 * 8, w0v.begin() + (size_t)(W0_HEAD + 1) * 64 * 8);
+        if (R > 0) std::copy(conv16p.begin(), conv16p.begin() + 8 * 64 * 8, w0v.begin() + (size_t)W0_TOWER * 64 * 8);
+    }
     std::vector<float> stem_b(desc->stem_b, desc->stem_b + FW), conv_b(desc->conv_b, desc->conv_b + (size_t)2 * R * FW),
         head_b(4, 0.0f), mlp((size_t)MLP_F4 * 4, 0.0f);
     for (int i = 0; i < 3; ++i) head_b[i] = desc->head_b[i];
@@ -262,6 +284,8 @@ int c4_net_create(int device, const c4_net_desc *desc, c4_net **out)
     UP16(stem, stem_w) UP16(conv, conv_w) UP16(head, head_w)
     UP16(stem16, stem_w16) UP16(conv16, conv_w16) UP16(head16, head_w16)
     UP16(stem16l, stem_w16l) UP16(conv16l, conv_w16l) UP16(head16l, head_w16l)
+    UP16(conv16p, conv_w16p) UP16(w0v, w0)
+    net->d.conv_w16p_bytes = (unsigned)(conv16p.size() * sizeof(_Float16));
     UP32(stem_b, stem_b) UP32(conv_b, conv_b) UP32(head_b, head_b)
     {
         const float *pm = nullptr;
@@ -333,12 +357,14 @@ int c4_net_forward_wave(c4_net *net, void *hip_stream, const uint64_t *color0_de
         return C4_EINVAL;
     }
     if (n == 0) return C4_OK;
+    const char *ea16 = getenv("C4_NET_WAVE_ACTIVE");   // timing experiments only: fewer waves per CU
+    const int active = ea16 ? atoi(ea16) : NWAVES;
     if (net->d.mode != NETMODE_F32_F16) {
         const dim3 g1((n + NWAVES - 1) / NWAVES), b1(NTHREADS);
         if (net->d.mode == NETMODE_F64)
-            hipLaunchKernelGGL(c4_net_wave1_kernel<NETMODE_F64>, g1, b1, 0, (hipStream_t)hip_stream, net->d, color0_dev, color1_dev, (int)n, values_dev, priors_dev);
+            hipLaunchKernelGGL(c4_net_wave1_kernel<NETMODE_F64>, g1, b1, 0, (hipStream_t)hip_stream, net->d, color0_dev, color1_dev, (int)n, values_dev, priors_dev, active);
         else
-            hipLaunchKernelGGL(c4_net_wave1_kernel<NETMODE_F32_PRECISE>, g1, b1, 0, (hipStream_t)hip_stream, net->d, color0_dev, color1_dev, (int)n, values_dev, priors_dev);
+            hipLaunchKernelGGL(c4_net_wave1_kernel<NETMODE_F32_PRECISE>, g1, b1, 0, (hipStream_t)hip_stream, net->d, color0_dev, color1_dev, (int)n, values_dev, priors_dev, active);
         hipError_t pr = hipGetLastError();
         if (pr != hipSuccess) {
             snprintf(n_err, 512, "c4_net_wave1_kernel launch failed: %s", hipGetErrorString(pr));
@@ -346,9 +372,8 @@ int c4_net_forward_wave(c4_net *net, void *hip_stream, const uint64_t *color0_de
         }
         return C4_OK;
     }
-    const char *ea16 = getenv("C4_NET_WAVE_ACTIVE");   // timing experiments only: fewer waves per CU
     hipLaunchKernelGGL(c4_net_wave16_kernel, dim3((n + NWAVES - 1) / NWAVES), dim3(NTHREADS), 0, (hipStream_t)hip_stream, net->d,
-                       color0_dev, color1_dev, (int)n, values_dev, priors_dev, ea16 ? atoi(ea16) : NWAVES);
+                       color0_dev, color1_dev, (int)n, values_dev, priors_dev, active);
     hipError_t r = hipGetLastError();
     if (r != hipSuccess) {
         snprintf(n_err, 512, "c4_net_wave16_kernel launch failed: %s", hipGetErrorString(r));

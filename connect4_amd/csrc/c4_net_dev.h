@@ -48,6 +48,11 @@ struct NetDev {
     const half8 *stem_w16, *conv_w16, *head_w16;
     // ... and, for the reference-precision mode, their scaled low parts (net_forward_wave16p)
     const half8 *stem_w16l, *conv_w16l, *head_w16l;
+    // ... and the tower as ONE linear stream for net_forward_wave16q: per tower tap T four fragments
+    // [cout tile 0 hi][cout tile 0 lo][cout tile 1 hi][cout tile 1 lo] x 64 lanes x 16 bytes = 4,096 bytes
+    const half8 *conv_w16p;
+    unsigned conv_w16p_bytes;
+    const half8 *w0;   // [W0_FRAGS][64]: the fragments a reference-precision pass needs first (stem hi/lo, heads hi/lo, tower taps 0 and 1)
     unsigned long long *stamps;   // diagnostic only (C4_NET_STAMPS=1): [wave][16] s_memtime values of block 0
 };
 
@@ -938,6 +943,7 @@ __device__ __forceinline__ void net_forward_wave16p(const NetDev &nd, _Float16 *
 #pragma unroll
             for (int rt = 0; rt < RT16; ++rt) { bh[rt] = nh[rt]; bl[rt] = nl[rt]; }
         }
+        if (L == C4_NET_STAMP_LAYER) stamp(12);
         if (second) {   // + block input (lives in dh/dl): identity MFMAs keep it exact in both accumulators
 #pragma unroll
             for (int rt = 0; rt < RT16; ++rt) {
@@ -953,10 +959,12 @@ __device__ __forceinline__ void net_forward_wave16p(const NetDev &nd, _Float16 *
                 }
             }
         }
+        if (L == C4_NET_STAMP_LAYER) stamp(13);
 #pragma unroll
         for (int rt = 0; rt < RT16; ++rt)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) store16p(ah[rt][ct], al[rt][ct], dh, dl, rbase[rt] + 16 * ct + 4 * g, real[rt]);
+        if (L == C4_NET_STAMP_LAYER) stamp(14);
         if (L < 6) stamp(2 + L);
     };
     for (int blk = 0; blk < nd.n_res; ++blk) {
@@ -1007,6 +1015,339 @@ __device__ __forceinline__ void net_forward_wave16p(const NetDev &nd, _Float16 *
         for (int c = 0; c < 11; ++c) {
             const float wv = pt[c * 64 + lane];      // zero where seg*11 + c >= 84 or (lane & 7) == 7
             const int cc = seg * 11 + c < 2 * PIX ? c : 2 * PIX - 1 - seg * 11;
+            l0 += wv * hpA[cc];
+        }
+        l0 += dppf<0x128>(l0);
+#pragma unroll
+        for (int m = 16; m <= 32; m <<= 1) l0 += __shfl_xor(l0, m, 64);
+        const float fb = vt_b[lane], vw = vt_b[64 + lane], pb = vt_b[128 + lane];
+        const bool is_pol = lane < 7;
+        const float a = v0 + fb;
+        const float lg = l0 + pb;
+        const float rs = sum16(lane < PIX ? vw * lrelu(a) : 0.0f);               // model.py:83-85
+        const float vsum = readlane_f(rs, 0) + readlane_f(rs, 16) + readlane_f(rs, 32);
+        const float value = (tanhf(vsum + nd.vout_b) + nd.w1) * nd.w2;           // model.py:86-88
+        const float mx = max8(is_pol ? lg : -INFINITY);
+        const float e = is_pol ? expf(lg - mx) : 0.0f;
+        const float sum = sum8(e);
+        if (lane == 0) values[out] = value;
+        if (is_pol) priors[(size_t)out * 7 + lane] = e / sum;
+    }
+    stamp(10);
+}
+
+// ------------------------------------------------------------------------------------------------
+// net_forward_wave16q: net_forward_wave16p's arithmetic, operation for operation (same products, same accumulation
+// order per accumulator, same roundings: bit-identical answers), with a leaner instruction stream -- one wave on a SIMD
+// cannot issue its MFMAs back to back when ~30 other instructions per tap stand between them (round 3: 4.0-4.6 k
+// cycles per layer's k-loop against 2.6 k of MFMA time, alone on a CU as well as inside the self-play kernel):
+//   * the tower's weights are ONE linear stream read with buffer loads: scalar tap offset + a lane offset fixed for the
+//     whole pass + an immediate per fragment -- no 64-bit vector address arithmetic per load (and no MFMA-operand /
+//     address register hazards with their s_nops), no clamp at the end of the tower (a buffer load past the end of the
+//     stream returns zeros);
+//   * what a pass needs FIRST -- the stem's and the heads' fragments, the tower's first two taps -- lives in LDS for the whole
+//     launch (18 KB per workgroup, stage_w0_lds): a pass no longer starts with an L2 round trip in front of its first MFMA;
+//   * group barriers spread the next tap's operand reads and the weight requests between the MFMAs instead of in
+//     clusters in front of them (C4_F32X3_SGB);
+//   * the epilogue runs on packed float32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two values per
+//     instruction; hi + lo * 2^-11 as ONE fma -- the product is exact, so the rounding is the add's).
+// ------------------------------------------------------------------------------------------------
+#ifndef C4_F32X3_LEAN
+#define C4_F32X3_LEAN 1
+#endif
+#ifndef C4_F32X3_SGB
+#define C4_F32X3_SGB 1
+#endif
+#ifndef C4_F32X3_PKEPI
+#define C4_F32X3_PKEPI 1
+#endif
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+// The fragments every pass needs first -- stem (hi 4, lo 4), heads (hi, lo), the tower's first two taps (2 x 4) -- live in LDS
+// for the whole launch (W0_FRAGS x 64 lanes x 16 bytes = 18 KB per workgroup, staged once by stage_w0_lds): a pass starts with
+// LDS reads instead of an L2 round trip in front of its first MFMA, and nothing has to stay in registers between passes.
+constexpr int W0_STEM = 0, W0_HEAD = 8, W0_TOWER = 10, W0_FRAGS = 18;
+__device__ __forceinline__ half8 wq_load(const __amdgpu_buffer_rsrc_t &r, int voff, int soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return __builtin_bit_cast(half8, v);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wq_rsrc(const NetDev &nd)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)nd.conv_w16p, 0, (int)nd.conv_w16p_bytes, 0x00020000);
+}
+// cooperative fill by the whole workgroup (the caller synchronises afterwards)
+__device__ __forceinline__ void stage_w0_lds(const NetDev &nd, half8 *w0)
+{
+    for (int i = threadIdx.x; i < W0_FRAGS * 64; i += blockDim.x) w0[i] = nd.w0[i];
+}
+
+__device__ __forceinline__ void store16q(const floatx4 &hi, const floatx4 &lo, _Float16 *dh, _Float16 *dl, int off, bool real)
+{
+#if C4_F32X3_PKEPI
+    half4 oh, ol;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float2v h = {hi[2 * i], hi[2 * i + 1]}, l = {lo[2 * i], lo[2 * i + 1]};
+        const float2v inv = {LO_INV, LO_INV}, leak = {LEAK, LEAK}, sc = {LO_SCALE, LO_SCALE};
+        float2v y = __builtin_elementwise_fma(l, inv, h);     // = hi + lo * 2^-11 (the product is exact)
+        const float2v ly = y * leak;
+        asm("v_max_f32 %0, %1, %2" : "=v"(y.x) : "v"(y.x), "v"(ly.x));
+        asm("v_max_f32 %0, %1, %2" : "=v"(y.y) : "v"(y.y), "v"(ly.y));
+        const half2v yh = __builtin_convertvector(y, half2v);
+        const float2v back = __builtin_convertvector(yh, float2v);
+        const float2v rl = (y - back) * sc;
+        const half2v yl = __builtin_convertvector(rl, half2v);
+        oh[2 * i] = yh.x; oh[2 * i + 1] = yh.y;
+        ol[2 * i] = yl.x; ol[2 * i + 1] = yl.y;
+    }
+    if (real) {
+        *reinterpret_cast<half4 *>(dh + off) = oh;
+        *reinterpret_cast<half4 *>(dl + off) = ol;
+    }
+#else
+    store16p(hi, lo, dh, dl, off, real);
+#endif
+}
+
+__device__ __forceinline__ void net_forward_wave16q(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds,
+                                                    const uint16_t *tab, uint64_t b0, uint64_t b1, float *__restrict__ values,
+                                                    float *__restrict__ priors, int out, const half8 *w0, unsigned long long *stamps = nullptr)
+{
+    int lane_ = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_));     // keep lane-derived addresses out of a persistent caller's loop (see net_forward_wave16)
+    const int lane = lane_;
+    const int n = lane & 15, g = lane >> 4;
+    auto stamp = [&](int i) { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
+    const int n_layers = 2 * nd.n_res;
+    _Float16 *const p0h = buf, *const p0l = buf + PLANE16, *const p1h = buf + 2 * PLANE16, *const p1l = buf + 3 * PLANE16;
+    const __amdgpu_buffer_rsrc_t wr = wq_rsrc(nd);
+    const int voff = lane * 16;
+    int soff = 2 * 4096;                // stream offset of the tap the NEXT refill requests (a request past the end of the tower returns zeros)
+    // rolling weight window, slot = tower tap % 3; taps 0 and 1 come from LDS, slot 2 is requested by the first tap
+    half8 wh[WTAPS][2], wl[WTAPS][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            wh[t][ct] = w0[(W0_TOWER + t * 4 + 2 * ct) * 64 + lane];
+            wl[t][ct] = w0[(W0_TOWER + t * 4 + 2 * ct + 1) * 64 + lane];
+        }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) { wh[2][ct] = wh[0][ct]; wl[2][ct] = wl[0][ct]; }
+    half8 swh[4], swl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { swh[i] = w0[(W0_STEM + i) * 64 + lane]; swl[i] = w0[(W0_STEM + 4 + i) * 64 + lane]; }
+    const float hb0 = nd.head_b[0], hb1 = nd.head_b[1], hb2 = nd.head_b[2];
+    uint32_t tb[TAB16 / 2];
+    {
+        const uint4 *t4 = reinterpret_cast<const uint4 *>(tab + lane * TAB16);
+#pragma unroll
+        for (int i = 0; i < TAB16 / 8; ++i) { const uint4 v = t4[i]; tb[4 * i] = v.x; tb[4 * i + 1] = v.y; tb[4 * i + 2] = v.z; tb[4 * i + 3] = v.w; }
+    }
+    auto tof = [&](int idx) -> int { return (int)((tb[idx >> 1] >> (16 * (idx & 1))) & 0xffffu); };
+    // input planes (board.py:147-154), 4 halves per row, at the start of p1h (the tower writes it only after the stem)
+    _Float16 *inp = p1h;
+    if (lane <= PIX) {
+        half4 v = {};
+        if (lane < PIX) {
+            const int y = lane / 7, x = lane - y * 7;
+            const int bit = x * 7 + (5 - y);
+            v[0] = (_Float16)((__popcll(b0 | b1) & 1) ? 0.0f : 1.0f);
+            v[1] = (_Float16)(float)((b0 >> bit) & 1);
+            v[2] = (_Float16)(float)((b1 >> bit) & 1);
+        }
+        *reinterpret_cast<half4 *>(inp + lane * 4) = v;   // lane == PIX: the zero row of the planes
+    }
+    if (lane < CS16) {
+        p0h[PIX * CS16 + lane] = (_Float16)0.0f; p0l[PIX * CS16 + lane] = (_Float16)0.0f;
+        p1h[PIX * CS16 + lane] = (_Float16)0.0f; p1l[PIX * CS16 + lane] = (_Float16)0.0f;
+    }
+    bool real[RT16];
+    int rbase[RT16];
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt) {
+        real[rt] = 16 * rt + n < PIX;
+        rbase[rt] = (real[rt] ? 16 * rt + n : PIX) * CS16;
+    }
+    auto bias4 = [&](const float *b, int ct) -> floatx4 {
+        const float4 v = *reinterpret_cast<const float4 *>(b + 16 * ct + 4 * g);
+        return floatx4{v.x, v.y, v.z, v.w};
+    };
+    const floatx4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    // ------------------------------------------------------------------ stem (0/1 inputs: two MFMAs per step)
+    {
+        floatx4 ah[RT16][2], al[RT16][2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const floatx4 bv = bias4(bias_lds, ct);
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) { ah[rt][ct] = bv; al[rt][ct] = zero4; }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) {
+                const half4 va = *reinterpret_cast<const half4 *>(inp + tof(27 + rt * 4 + s * 2));
+                const half4 vb = *reinterpret_cast<const half4 *>(inp + tof(27 + rt * 4 + s * 2 + 1));
+                half8 bf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bf[j] = va[j]; bf[4 + j] = vb[j]; }
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    ah[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[s * 2 + ct], bf, ah[rt][ct], 0, 0, 0);
+                    al[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[s * 2 + ct], bf, al[rt][ct], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) store16q(ah[rt][ct], al[rt][ct], p0h, p0l, rbase[rt] + 16 * ct + 4 * g, real[rt]);
+    }
+    stamp(1);
+    // ------------------------------------------------------------------ residual tower
+    auto layer = [&](auto second_tag, const int L) {
+        constexpr bool second = decltype(second_tag)::value;
+        const _Float16 *sh = second ? p1h : p0h, *sl = second ? p1l : p0l;
+        _Float16 *dh = second ? p0h : p1h, *dl = second ? p0l : p1l;
+        floatx4 ah[RT16][2], al[RT16][2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const floatx4 bv = bias4(bias_lds + F * (1 + L), ct);
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) { ah[rt][ct] = bv; al[rt][ct] = zero4; }
+        }
+        half8 bh[RT16], bl[RT16], nh[RT16], nl[RT16];
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt) {
+            bh[rt] = *reinterpret_cast<const half8 *>(sh + tof(rt * 9));
+            bl[rt] = *reinterpret_cast<const half8 *>(sl + tof(rt * 9));
+        }
+#if C4_F32X3_SGB
+        __builtin_amdgcn_sched_barrier(0);   // the group barriers below order the k-loop's own reads: the first tap's stay in front of it
+#endif
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            {   // refill: the slot the PREVIOUS tap used gets the tap two ahead of this one
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    wh[(t + 2) % WTAPS][ct] = wq_load(wr, voff + (2 * ct) * 1024, soff);
+                    wl[(t + 2) % WTAPS][ct] = wq_load(wr, voff + (2 * ct + 1) * 1024, soff);
+                }
+                soff += 4096;
+            }
+            if (t + 1 < 9) {
+#pragma unroll
+                for (int rt = 0; rt < RT16; ++rt) {
+                    nh[rt] = *reinterpret_cast<const half8 *>(sh + tof(rt * 9 + t + 1));
+                    nl[rt] = *reinterpret_cast<const half8 *>(sl + tof(rt * 9 + t + 1));
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const half8 cwh = wh[t % WTAPS][ct], cwl = wl[t % WTAPS][ct];
+#pragma unroll
+                for (int rt = 0; rt < RT16; ++rt) {
+                    ah[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cwh, bh[rt], ah[rt][ct], 0, 0, 0);
+                    al[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cwl, bh[rt], al[rt][ct], 0, 0, 0);
+                    al[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cwh, bl[rt], al[rt][ct], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) { bh[rt] = nh[rt]; bl[rt] = nl[rt]; }
+#if C4_F32X3_SGB
+            // this tap's instruction order: the four weight requests behind the first MFMAs, then one operand read of the
+            // next tap per two MFMAs
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+            if (t + 1 < 9) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);
+            }
+#endif
+        }
+#if C4_F32X3_SGB
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (L == C4_NET_STAMP_LAYER) stamp(12);
+        if (second) {   // + block input (lives in dh/dl): identity MFMAs keep it exact in both accumulators
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) {
+                const half8 xh = *reinterpret_cast<const half8 *>(dh + rbase[rt] + 8 * g);
+                const half8 xl = *reinterpret_cast<const half8 *>(dl + rbase[rt] + 8 * g);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    half8 idf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) idf[j] = (_Float16)((8 * g + j) == 16 * ct + n ? 1.0f : 0.0f);
+                    ah[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(idf, xh, ah[rt][ct], 0, 0, 0);
+                    al[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(idf, xl, al[rt][ct], 0, 0, 0);
+                }
+            }
+        }
+        if (L == C4_NET_STAMP_LAYER) stamp(13);
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) store16q(ah[rt][ct], al[rt][ct], dh, dl, rbase[rt] + 16 * ct + 4 * g, real[rt]);
+        if (L == C4_NET_STAMP_LAYER) stamp(14);
+        if (L < 6) stamp(2 + L);
+    };
+    for (int blk = 0; blk < nd.n_res; ++blk) {
+        layer(std::false_type{}, 2 * blk);
+        layer(std::true_type{}, 2 * blk + 1);
+    }
+    stamp(8);
+    // ------------------------------------------------------------------ 1x1 head convs
+    float *hs = reinterpret_cast<float *>(p1h);   // [HSTR] fp32 (p1 is free)
+    {
+        const half8 hwh = w0[W0_HEAD * 64 + lane], hwl = w0[(W0_HEAD + 1) * 64 + lane];
+        floatx4 a[RT16], b[RT16];
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt) {
+            const half8 xh = *reinterpret_cast<const half8 *>(p0h + rbase[rt] + 8 * g);
+            const half8 xl = *reinterpret_cast<const half8 *>(p0l + rbase[rt] + 8 * g);
+            a[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwh, xh, zero4, 0, 0, 0);
+            b[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwl, xh, zero4, 0, 0, 0);
+            b[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwh, xl, b[rt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt) {
+            const int r = 16 * rt + n;
+            if (g == 0 && r < PIX) {
+                hs[0 * PIX + r] = lrelu(a[rt][0] + b[rt][0] * LO_INV + hb0);
+                hs[1 * PIX + r] = lrelu(a[rt][1] + b[rt][1] * LO_INV + hb1);
+                hs[2 * PIX + r] = lrelu(a[rt][2] + b[rt][2] * LO_INV + hb2);
+            }
+        }
+        if (lane < 2) hs[HEADV + lane] = 0.0f;   // pad 126,127
+    }
+    stamp(9);
+    // ------------------------------------------------------------------ MLP heads (fp32 VALU), as in net_forward_block
+    {
+        const float *vt_b = reinterpret_cast<const float *>(mlp + VT_F4 + PT_F / 4);   // fc_b | vout_w | pfc_b
+        const float *pt = reinterpret_cast<const float *>(mlp + VT_F4);
+        const float4 *hA4 = reinterpret_cast<const float4 *>(hs);
+        float v0 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 11; ++q) {
+            const float4 wv = mlp[q * 64 + lane];
+            const float4 xa = hA4[q];
+            v0 += wv.x * xa.x + wv.y * xa.y + wv.z * xa.z + wv.w * xa.w;
+        }
+        const int seg = lane >> 3;
+        const float *hpA = hs + PIX + seg * 11;
+        float l0 = 0.0f;
+#pragma unroll
+        for (int cc0 = 0; cc0 < 11; ++cc0) {
+            const float wv = pt[cc0 * 64 + lane];      // zero where seg*11 + c >= 84 or (lane & 7) == 7
+            const int cc = seg * 11 + cc0 < 2 * PIX ? cc0 : 2 * PIX - 1 - seg * 11;
             l0 += wv * hpA[cc];
         }
         l0 += dppf<0x128>(l0);
@@ -1261,14 +1602,22 @@ __device__ __forceinline__ void net_forward_wave16w(const NetDev &nd, _Float16 *
 constexpr int NETMODE_F32_F16 = 0;    // 32 filters, fp16 storage: net_forward_wave16 / net_forward_block
 constexpr int NETMODE_F32_PRECISE = 1;
 constexpr int NETMODE_F64 = 2;        // 64 filters, fp16 storage, one position per pass
+// LDS for the fragments a pass needs first (only the reference-precision forward keeps any)
+template <int MODE> struct W0Lds { static constexpr int FRAGS = (MODE == NETMODE_F32_PRECISE && C4_F32X3_LEAN) ? W0_FRAGS * 64 : 1; };
 template <int MODE>
 __device__ __forceinline__ void net_forward_wave1_mode(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds,
                                                        const uint16_t *tab, uint64_t b0, uint64_t b1, float *__restrict__ values,
-                                                       float *__restrict__ priors, int out, unsigned long long *stamps = nullptr)
+                                                       float *__restrict__ priors, int out, const half8 *w0,
+                                                       unsigned long long *stamps = nullptr)
 {
-    if (MODE == NETMODE_F64) net_forward_wave16w(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, stamps);
-    else if (MODE == NETMODE_F32_PRECISE) net_forward_wave16p(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, stamps);
-    else net_forward_wave16(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, stamps);
+    if constexpr (MODE == NETMODE_F64) net_forward_wave16w(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, stamps);
+    else if constexpr (MODE == NETMODE_F32_PRECISE) {
+#if C4_F32X3_LEAN
+        net_forward_wave16q(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, w0, stamps);
+#else
+        net_forward_wave16p(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, stamps);
+#endif
+    } else net_forward_wave16(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, stamps);
 }
 // halves of private LDS a wave needs for its planes in each mode
 template <int MODE> struct WaveBuf {

@@ -6,6 +6,7 @@ and evaluates leaf batches straight from the engine's bitboard buffers:
 ``net.forward_bitboards(c0_ptr, c1_ptr, n, values, priors)``.
 """
 import ctypes as C
+from typing import Optional
 
 import numpy as np
 
@@ -18,15 +19,24 @@ class FusedNet:
 
     PRECISIONS = {"f16": 0, "f32x3": 1}
 
-    def __init__(self, state_dict, device: int = 0, precision: str = "f16"):
-        """precision: "f16" = fp16 storage / fp32 accumulation (one MFMA per k-step); "f32x3" = reference
-        precision: every fp32 operand split into fp16 hi + scaled lo parts, three MFMAs per k-step."""
+    @staticmethod
+    def default_precision(filters: int) -> str:
+        """The reference evaluates leaves in float32 (model.py:252-282), so the default is the mode that reproduces its
+        visit counts: "f32x3" wherever the engine offers it (32 filters); the 64-filter forward exists in fp16 storage only."""
+        return "f32x3" if filters == 32 else "f16"
+
+    def __init__(self, state_dict, device: int = 0, precision: Optional[str] = None):
+        """precision: "f32x3" = reference precision (the default at 32 filters): every fp32 operand split into fp16 hi +
+        scaled lo parts, three MFMAs per k-step, fp32 accumulation; "f16" = fp16 storage / fp32 accumulation (one MFMA
+        per k-step), opt-in: faster, answers within 2e-2 of the reference's instead of 5e-5."""
         import torch
+        sd = {k: v.detach().cpu() for k, v in state_dict.items()}
+        cfg = PolicyValueNet.config_from_state_dict(sd)
+        if precision is None:
+            precision = self.default_precision(cfg.filters)
         if precision not in self.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
         self.precision = precision
-        sd = {k: v.detach().cpu() for k, v in state_dict.items()}
-        cfg = PolicyValueNet.config_from_state_dict(sd)
         self.config = cfg
         self.device = device
 
@@ -107,14 +117,17 @@ class FusedNet:
             pass
 
 
-def make_selfplay_net(state_dict, device: int = 0, precision: str = "f16"):
-    """The fastest evaluator this build has for a checkpoint: the fused MFMA forwards for 32 filters (the
-    reference's default, config.py:8-12; fp16 or reference precision) and for 64 filters (its example_config,
-    data/example_config.py:8-16; fp16), up to 16 / 7 residual blocks (their biases live in LDS) and any number
-    of value-head Linear layers; anything else runs through the PyTorch-ROCm plan (connect4_amd.net.InferenceNet, fp32).  All plug into SelfPlay /
-    generate_games / DeviceNetEvaluator unchanged."""
+def make_selfplay_net(state_dict, device: int = 0, precision: Optional[str] = None):
+    """The fastest evaluator this build has for a checkpoint at the requested precision: the fused MFMA forwards for 32
+    filters (the reference's default, config.py:8-12; reference precision "f32x3" unless "f16" is asked for) and for
+    64 filters (its example_config, data/example_config.py:8-16; fp16 storage only, so precision=None or "f16"), up to
+    16 / 7 residual blocks (their biases live in LDS) and any number of value-head Linear layers; anything else -- and
+    64 filters with precision="f32x3" -- runs through the PyTorch-ROCm plan (connect4_amd.net.InferenceNet, fp32).
+    All plug into SelfPlay / generate_games / DeviceNetEvaluator unchanged."""
     import torch
     cfg = PolicyValueNet.config_from_state_dict(state_dict)
+    if precision is None:
+        precision = FusedNet.default_precision(cfg.filters)
     fits = (cfg.filters == 32 and cfg.n_residuals <= 16) or (cfg.filters == 64 and cfg.n_residuals <= 7 and precision == "f16")
     if cfg.channels == 3 and fits:
         return FusedNet(state_dict, device=device, precision=precision)

@@ -101,10 +101,42 @@ class Trainer:
                 loss = self.value_loss(xv, v) + self.prior_loss(xp, p)   # model.py:221-225
                 loss.backward()
                 self.optimiser.step()
-                last = float(loss.detach())
+                last = loss.detach()          # (read back once, after the last batch: no host synchronisation per step)
         self.scheduler.step()       # once per generation (model.py:239)
         self.net.eval()
-        return last
+        return None if last is None else float(last)
+
+    def state(self):
+        """The checkpoint dict of save() with CPU tensors (model.py:242-250)."""
+        def cpu(o):
+            if isinstance(o, torch.Tensor):
+                return o.detach().cpu()
+            if isinstance(o, dict):
+                return {k: cpu(v) for k, v in o.items()}
+            if isinstance(o, (list, tuple)):
+                return type(o)(cpu(v) for v in o)
+            return o
+        return {"net_state_dict": cpu(self.net.state_dict()), "optimiser_state_dict": cpu(self.optimiser.state_dict()),
+                "scheduler_state_dict": cpu(self.scheduler.state_dict())}
+
+    def load_state(self, ckpt):
+        self.net.load_state_dict(ckpt["net_state_dict"])
+        self.optimiser.load_state_dict(ckpt["optimiser_state_dict"])     # (moves the momentum buffers to the parameters' device)
+        self.scheduler.load_state_dict(ckpt["scheduler_state_dict"])
+
+    def broadcast_state(self, src: int = 0, extra=None):
+        """Every rank's trainer becomes rank `src`'s: net (weights, batch-norm statistics), optimiser (momentum buffers,
+        learning rate) and scheduler state travel as one object (~0.5 MB for the default net; torch.distributed, RCCL or
+        gloo).  The reference has ONE model per generation (training.py:147-153); ranks that trained by themselves would
+        drift apart (non-deterministic GPU reductions, unshared shuffles).  `extra` (e.g. the loss) rides along; returns
+        rank src's."""
+        import torch.distributed as dist
+        box = [(self.state(), extra) if dist.get_rank() == src else None]
+        on_gpu = dist.get_backend() == "nccl" and self.device.type == "cuda"     # RCCL moves the pickled bytes through this rank's GPU
+        dist.broadcast_object_list(box, src=src, device=self.device if on_gpu else None)
+        if dist.get_rank() != src:
+            self.load_state(box[0][0])
+        return box[0][1]
 
     def _set_valid_rows(self, k):
         from .net import _BatchNorm2d

@@ -778,3 +778,202 @@ void c4o_pool_stats(const c4o_pool *p, int64_t *sims, int64_t *expansions, int64
     if (moves) *moves = p->moves;
     if (evals) *evals = p->evals;
 }
+
+/* ------------------------------------------------------------------ lock-step REPLAY pool (parity tests at full size)
+ * n games of training_game.py:8-19, each with its own RNG tape (the tapes the device played with), advanced side by side.
+ * The evaluator is the reference's memoising Evaluator (evaluators.py:18-25): a position is asked for ONCE -- the caller
+ * answers it (with what the device's evaluation cache holds) -- and every later request of any game is served from the
+ * table.  c4o_replay_collect advances every unfinished game until it needs a position the table does not hold
+ * (OpenMP over games; the table is read-only then); c4o_replay_apply stores the answers and hands them to the games. */
+typedef struct {
+    c4o_board board;
+    c4o_tree *tree;
+    int sims_done, need_root, waiting, ply, result, failed;
+    c4o_board leaf;
+    c4o_move_record rec[42];
+} rgame;
+
+typedef struct { uint64_t c0, c1; float value; float prior[7]; } memo_entry;
+
+struct c4o_replay {
+    c4o_config cfg;
+    int n;
+    rgame *g;
+    const double *noise;   /* [n][42][7] */
+    const double *u;       /* [n][42] */
+    memo_entry *tab;       /* open addressing, key (c0, c1); c0 == c1 == ~0 marks an empty cell */
+    uint64_t cap, used;
+    int64_t lookups, hits;
+};
+
+static uint64_t memo_hash(uint64_t c0, uint64_t c1)
+{
+    uint64_t x = c0 * 0x9E3779B97F4A7C15ULL ^ (c1 + 0xD1B54A32D192ED03ULL) * 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 29;
+    x *= 0x94D049BB133111EBULL;
+    return x ^ (x >> 32);
+}
+static const memo_entry *memo_find(const c4o_replay *r, uint64_t c0, uint64_t c1)
+{
+    uint64_t i = memo_hash(c0, c1) & (r->cap - 1);
+    for (;;) {
+        const memo_entry *e = &r->tab[i];
+        if (e->c0 == c0 && e->c1 == c1) return e;
+        if (e->c0 == ~0ULL && e->c1 == ~0ULL) return NULL;
+        i = (i + 1) & (r->cap - 1);
+    }
+}
+static void memo_put_raw(memo_entry *tab, uint64_t cap, const memo_entry *v)
+{
+    uint64_t i = memo_hash(v->c0, v->c1) & (cap - 1);
+    while (!(tab[i].c0 == ~0ULL && tab[i].c1 == ~0ULL)) {
+        if (tab[i].c0 == v->c0 && tab[i].c1 == v->c1) return;   /* first answer wins (they are all the same net's) */
+        i = (i + 1) & (cap - 1);
+    }
+    tab[i] = *v;
+}
+static void memo_put(c4o_replay *r, const memo_entry *v)
+{
+    if (memo_find(r, v->c0, v->c1)) return;
+    if ((r->used + 1) * 2 > r->cap) {
+        uint64_t ncap = r->cap * 2;
+        memo_entry *nt = (memo_entry *)malloc(ncap * sizeof(memo_entry));
+        memset(nt, 0xFF, ncap * sizeof(memo_entry));
+        for (uint64_t i = 0; i < r->cap; ++i)
+            if (!(r->tab[i].c0 == ~0ULL && r->tab[i].c1 == ~0ULL)) memo_put_raw(nt, ncap, &r->tab[i]);
+        free(r->tab);
+        r->tab = nt;
+        r->cap = ncap;
+    }
+    memo_put_raw(r->tab, r->cap, v);
+    r->used++;
+}
+
+c4o_replay *c4o_replay_new(const c4o_config *cfg, int n_games, const double *noise_tapes, const double *u_tapes)
+{
+    c4o_replay *r = (c4o_replay *)calloc(1, sizeof(c4o_replay));
+    r->cfg = *cfg;
+    r->n = n_games;
+    r->g = (rgame *)calloc((size_t)n_games, sizeof(rgame));
+    r->noise = noise_tapes;
+    r->u = u_tapes;
+    r->cap = 1u << 16;
+    r->tab = (memo_entry *)malloc(r->cap * sizeof(memo_entry));
+    memset(r->tab, 0xFF, r->cap * sizeof(memo_entry));
+    for (int i = 0; i < n_games; ++i) { c4o_board_init(&r->g[i].board); r->g[i].result = C4O_NONE; }
+    return r;
+}
+
+void c4o_replay_free(c4o_replay *r)
+{
+    if (!r) return;
+    for (int i = 0; i < r->n; ++i) c4o_tree_free(r->g[i].tree);
+    free(r->g);
+    free(r->tab);
+    free(r);
+}
+
+static void replay_answer(c4o_replay *r, int i, const memo_entry *e)
+{
+    rgame *g = &r->g[i];
+    double pr[7];
+    for (int k = 0; k < 7; ++k) pr[k] = (double)e->prior[k];
+    if (g->need_root) {
+        const int use = r->cfg.root_dirichlet_alpha != 0.0 && r->cfg.root_exploration_fraction != 0.0;
+        c4o_tree_root_apply(g->tree, (double)e->value, pr, 1, (use && r->noise) ? r->noise + ((size_t)i * 42 + g->ply) * 7 : NULL);
+        g->need_root = 0;
+    } else {
+        c4o_tree_apply(g->tree, (double)e->value, pr, 1);
+        g->sims_done++;
+    }
+    g->waiting = 0;
+}
+
+/* training_game.py:8-19 for game i until it needs a position the table does not hold (returns 1) or has ended (0) */
+static int replay_advance(c4o_replay *r, int i, int64_t *lookups, int64_t *hits)
+{
+    rgame *g = &r->g[i];
+    if (g->failed || g->waiting) return g->waiting;
+    for (;;) {
+        if (!g->tree) {
+            if (g->board.result != C4O_NONE) { g->result = g->board.result; return 0; }
+            g->tree = c4o_tree_new(&r->cfg, &g->board);
+            g->sims_done = 0;
+            g->need_root = 1;
+            c4o_tree_root_request(g->tree, &g->leaf);
+        } else if (g->sims_done >= r->cfg.simulations) {
+            double av;
+            const int mv = c4o_tree_pick_move(g->tree, g->board.age, r->u ? r->u[(size_t)i * 42 + g->ply] : -1.0, &av);
+            if (mv < 0) { g->failed = 1; return 0; }
+            c4o_root_info info;
+            c4o_tree_root_info(g->tree, &info);
+            c4o_move_record *m = &g->rec[g->ply];
+            m->color0 = g->board.color[0];
+            m->color1 = g->board.color[1];
+            m->move = mv;
+            m->value = av;
+            for (int k = 0; k < 7; ++k) m->policy[k] = info.values_policy[k];
+            c4o_tree_free(g->tree);
+            g->tree = NULL;
+            c4o_make_move(&g->board, mv);
+            g->ply++;
+            continue;
+        } else if (!c4o_tree_select(g->tree, &g->leaf)) {   /* terminal leaf: the simulation is complete */
+            g->sims_done++;
+            continue;
+        }
+        (*lookups)++;
+        const memo_entry *e = memo_find(r, g->leaf.color[0], g->leaf.color[1]);
+        if (!e) { g->waiting = 1; return 1; }
+        (*hits)++;
+        replay_answer(r, i, e);
+    }
+}
+
+int c4o_replay_collect(c4o_replay *r, uint64_t *c0, uint64_t *c1, int32_t *game_of)
+{
+    int64_t lookups = 0, hits = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : lookups, hits)
+    for (int i = 0; i < r->n; ++i) replay_advance(r, i, &lookups, &hits);
+    r->lookups += lookups;
+    r->hits += hits;
+    int m = 0;
+    for (int i = 0; i < r->n; ++i)
+        if (r->g[i].waiting) { c0[m] = r->g[i].leaf.color[0]; c1[m] = r->g[i].leaf.color[1]; game_of[m] = i; m++; }
+    return m;
+}
+
+void c4o_replay_apply(c4o_replay *r, int m, const int32_t *game_of, const float *values, const float *priors)
+{
+    for (int j = 0; j < m; ++j) {
+        memo_entry e;
+        const rgame *g = &r->g[game_of[j]];
+        e.c0 = g->leaf.color[0];
+        e.c1 = g->leaf.color[1];
+        e.value = values[j];
+        for (int k = 0; k < 7; ++k) e.prior[k] = priors[(size_t)j * 7 + k];
+        memo_put(r, &e);
+    }
+    for (int j = 0; j < m; ++j) {
+        const int i = game_of[j];
+        const memo_entry *e = memo_find(r, r->g[i].leaf.color[0], r->g[i].leaf.color[1]);
+        replay_answer(r, i, e);
+    }
+}
+
+int c4o_replay_game(const c4o_replay *r, int i, c4o_move_record *rec, int *result)
+{
+    const rgame *g = &r->g[i];
+    if (g->failed) return -2;
+    if (g->result == C4O_NONE) return -1;
+    memcpy(rec, g->rec, sizeof(c4o_move_record) * (size_t)g->ply);
+    *result = g->result;
+    return g->ply;
+}
+
+void c4o_replay_stats(const c4o_replay *r, int64_t *lookups, int64_t *hits, int64_t *table_entries)
+{
+    if (lookups) *lookups = r->lookups;
+    if (hits) *hits = r->hits;
+    if (table_entries) *table_entries = (int64_t)r->used;
+}

@@ -149,6 +149,21 @@ void      c4o_pool_apply(c4o_pool *p, const float *values, const float *priors);
 void      c4o_pool_stats(const c4o_pool *p, int64_t *sims, int64_t *expansions, int64_t *games,
                          int64_t *moves, int64_t *evals);
 
+/* ---- lock-step replay pool (parity tests at full size): n tape-driven games of training_game.py:8-19 behind ONE
+ * memoising evaluator table (evaluators.py:18-25).  Protocol:
+ *   m = c4o_replay_collect(r, c0, c1, game_of)   every unfinished game runs until it needs a position the table lacks;
+ *                                                m such positions come back (arrays of capacity n); 0 = all games ended
+ *   c4o_replay_apply(r, m, game_of, values, priors)   the caller's answers (float32, as a net gives them)
+ *   c4o_replay_game(r, i, rec, &result)               the game's plies (returns its length; < 0: not finished / failed) */
+typedef struct c4o_replay c4o_replay;
+c4o_replay *c4o_replay_new(const c4o_config *cfg, int n_games, const double *noise_tapes /* [n][42][7] or NULL */,
+                           const double *u_tapes /* [n][42] or NULL */);
+void        c4o_replay_free(c4o_replay *r);
+int         c4o_replay_collect(c4o_replay *r, uint64_t *c0, uint64_t *c1, int32_t *game_of);
+void        c4o_replay_apply(c4o_replay *r, int m, const int32_t *game_of, const float *values, const float *priors);
+int         c4o_replay_game(const c4o_replay *r, int i, c4o_move_record *rec /* cap 42 */, int *result);
+void        c4o_replay_stats(const c4o_replay *r, int64_t *lookups, int64_t *hits, int64_t *table_entries);
+
 #ifdef __cplusplus
 }
 #endif

@@ -140,6 +140,13 @@ def lib():
         L.c4o_pool_collect.argtypes = [C.c_void_p, C.c_void_p]
         L.c4o_pool_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.c4o_pool_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_int64)] * 5
+        L.c4o_replay_new.argtypes = [C.POINTER(Config), C.c_int, C.c_void_p, C.c_void_p]
+        L.c4o_replay_new.restype = C.c_void_p
+        L.c4o_replay_free.argtypes = [C.c_void_p]
+        L.c4o_replay_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.c4o_replay_apply.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.c4o_replay_game.argtypes = [C.c_void_p, C.c_int, C.POINTER(MoveRecord), C.POINTER(C.c_int)]
+        L.c4o_replay_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_int64)] * 3
         _lib = L
     return _lib
 
@@ -300,6 +307,64 @@ class Pool:
     def close(self):
         if self._p:
             lib().c4o_pool_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ReplayPool:
+    """n tape-driven games of training_game.py:8-19 side by side behind one memoising evaluator table
+    (evaluators.py:18-25): collect() -> positions the table lacks -> caller answers -> apply()."""
+
+    def __init__(self, cfg, n_games, noise_tapes=None, u_tapes=None):
+        self.n = n_games
+        self._noise = None if noise_tapes is None else np.ascontiguousarray(noise_tapes, dtype=np.float64)
+        self._u = None if u_tapes is None else np.ascontiguousarray(u_tapes, dtype=np.float64)
+        if self._noise is not None:
+            assert self._noise.shape == (n_games, 42, 7)
+        if self._u is not None:
+            assert self._u.shape == (n_games, 42)
+        self._cfg = cfg
+        self._p = lib().c4o_replay_new(C.byref(cfg), n_games,
+                                       None if self._noise is None else self._noise.ctypes.data,
+                                       None if self._u is None else self._u.ctypes.data)
+        self.c0 = np.zeros(n_games, dtype=np.uint64)
+        self.c1 = np.zeros(n_games, dtype=np.uint64)
+        self.game_of = np.zeros(n_games, dtype=np.int32)
+
+    def collect(self):
+        """Number m of positions wanted; they are c0[:m], c1[:m] (for games game_of[:m]).  0 = every game has ended."""
+        return lib().c4o_replay_collect(self._p, self.c0.ctypes.data, self.c1.ctypes.data, self.game_of.ctypes.data)
+
+    def apply(self, m, values, priors):
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        p = np.ascontiguousarray(priors, dtype=np.float32)
+        assert v.shape == (m,) and p.shape == (m, 7)
+        lib().c4o_replay_apply(self._p, m, self.game_of.ctypes.data, v.ctypes.data, p.ctypes.data)
+
+    def game(self, i):
+        rec = (MoveRecord * 42)()
+        res = C.c_int()
+        n = lib().c4o_replay_game(self._p, i, rec, C.byref(res))
+        if n < 0:
+            raise RuntimeError("replay game %d did not finish (rc=%d)" % (i, n))
+        return dict(moves=[rec[k].move for k in range(n)],
+                    boards=[(int(rec[k].color0), int(rec[k].color1)) for k in range(n)],
+                    values=[rec[k].value for k in range(n)],
+                    policies=[list(rec[k].policy) for k in range(n)], result=res.value)
+
+    def stats(self):
+        vals = [C.c_int64() for _ in range(3)]
+        lib().c4o_replay_stats(self._p, *[C.byref(v) for v in vals])
+        return dict(zip(("lookups", "hits", "table_entries"), [v.value for v in vals]))
+
+    def close(self):
+        if self._p:
+            lib().c4o_replay_free(self._p)
             self._p = None
 
     def __del__(self):

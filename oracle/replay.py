@@ -47,3 +47,43 @@ def replay_game(ocfg, engine, net, rec, noise, u):
         assert (np.isnan(g["values"][i]) and np.isnan(rec.value[i])) or g["values"][i] == rec.value[i], "values differ"
         assert g["policies"][i] == list(rec.policy[i]), "policies differ"
     return stats
+
+
+def replay_games_bulk(ocfg, engine, net, recs, noise, u, threads=None):
+    """replay_game for MANY games at once: the oracle's lock-step replay pool (OpenMP over games, one memoising evaluator
+    table as in evaluators.py:18-25) asks for every position once; each batch of new positions is answered with what the
+    device's evaluation cache holds (one c4_eval_cache_lookup per batch; the net for entries the table has since lost).
+    Asserts that the oracle plays exactly the given records.  Returns dict(games, positions_asked, lost_by_the_table, ...)."""
+    if threads:
+        oc.set_threads(threads)
+    ids = [int(r.game_id) for r in recs]
+    pool = oc.ReplayPool(ocfg, len(recs), np.ascontiguousarray(noise[ids]), np.ascontiguousarray(u[ids]))
+    asked = lost = rounds = 0
+    try:
+        while True:
+            m = pool.collect()
+            if m == 0:
+                break
+            c0, c1 = pool.c0[:m].copy(), pool.c1[:m].copy()
+            v, p, found = engine.cache_lookup(c0, c1)
+            if not found.all():
+                miss = np.nonzero(~found)[0]
+                nv, npr = net.evaluate_bits(c0[miss], c1[miss], wave=True)
+                v[miss], p[miss] = nv, npr
+                lost += len(miss)
+            asked += m
+            rounds += 1
+            pool.apply(m, v, p)
+        for j, rec in enumerate(recs):
+            g = pool.game(j)
+            n = rec.length
+            assert g["moves"] == list(rec.move[:n]), "game %d: moves differ from the oracle's" % rec.game_id
+            assert g["boards"] == [(int(rec.color0[i]), int(rec.color1[i])) for i in range(n)], "game %d: boards differ" % rec.game_id
+            assert g["result"] == rec.result, "game %d: result differs" % rec.game_id
+            for i in range(n):
+                assert (np.isnan(g["values"][i]) and np.isnan(rec.value[i])) or g["values"][i] == rec.value[i], "game %d: values differ" % rec.game_id
+                assert g["policies"][i] == list(rec.policy[i]), "game %d: policies differ" % rec.game_id
+        st = pool.stats()
+    finally:
+        pool.close()
+    return dict(games=len(recs), positions_asked=asked, lost_by_the_table=lost, rounds=rounds, evaluator_calls=st["lookups"])

@@ -1,5 +1,6 @@
-"""N>1 path on CPU: world_size-2 gloo run of the shard arithmetic and the end-of-generation
-all-gather of finished-game records (the only exchange in the design; none inside the rollouts)."""
+"""N>1 path on CPU: world_size-2 and -8 gloo runs of the shard arithmetic, the end-of-generation all-gather of
+finished-game records (none inside the rollouts) and the broadcast of the trained model (one model per generation, as in
+the reference: training.py:147-153)."""
 import os
 import socket
 
@@ -85,3 +86,94 @@ def test_all_gather_games_world2():
             expect.append((g.game_id + start, g.moves, g.result.value, g.values,
                            [b.to_int_tuple() for b in g.boards], [p.tolist() for p in g.priors]))
     assert games == expect
+
+
+def test_all_gather_games_world8():
+    """The 8-GPU shape (BASELINE configs[2]/[4]) rehearsed on CPU: eight ranks, disjoint seed+rank streams, contiguous id
+    ranges that differ in size by at most one, every rank ends up with the same list in global id order."""
+    world, n_games = 8, 21
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_games, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    outs.sort()
+    spans = [(o[1], o[2]) for o in outs]
+    assert spans == [(0, 3), (3, 3), (6, 3), (9, 3), (12, 3), (15, 2), (17, 2), (19, 2)]
+    assert [o[3] for o in outs] == list(range(7, 15)) and len(set(o[3] for o in outs)) == world   # seed + rank: disjoint streams
+    for o in outs[1:]:
+        assert o[4] == outs[0][4]
+    games = outs[0][4]
+    assert [g[0] for g in games] == list(range(n_games))
+    expect = []
+    for r, (start, count) in enumerate(spans):
+        for g in _fake_games(r, count):
+            expect.append((g.game_id + start, g.moves, g.result.value, g.values,
+                           [b.to_int_tuple() for b in g.boards], [p.tolist() for p in g.priors]))
+    assert games == expect
+
+
+def _train_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from connect4_amd.net import NetConfig
+    from connect4_amd.training import ModelConfig, Trainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                      # every rank starts from DIFFERENT weights and a different shuffle stream
+    tr = Trainer(ModelConfig(net_config=NetConfig(filters=8, n_residuals=1), batch_size=16, n_training_epochs=2, milestones=(1, 3)),
+                 device="cpu")
+    loss = None
+    if rank == 0:                                      # one model: rank 0 trains (run_generation), the others wait
+        g = torch.Generator().manual_seed(5)
+        boards = (torch.rand(40, 3, 6, 7, generator=g) > 0.5).float()
+        values = torch.rand(40, generator=g)
+        priors = torch.softmax(torch.rand(40, 7, generator=g), 1)
+        loss = tr.train(boards, values, priors)
+    loss = tr.broadcast_state(src=0, extra=loss)
+    st = tr.state()
+    flat = {"net." + k: v for k, v in st["net_state_dict"].items()}
+    for i, ps in st["optimiser_state_dict"]["state"].items():
+        flat["momentum.%s" % i] = ps["momentum_buffer"]
+    q.put((rank, loss, {k: v.double().sum().item() for k, v in flat.items()}, {k: v.numpy().tobytes() for k, v in flat.items()},
+           st["optimiser_state_dict"]["param_groups"][0]["lr"], st["scheduler_state_dict"]["last_epoch"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trained_state_is_broadcast_to_every_rank():
+    """after a generation every rank must hold rank 0's net, batch-norm statistics, momentum buffers,
+    learning rate and scheduler step -- bit for bit -- or the next generation's shards are played by different nets."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in range(world)], key=lambda o: o[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    a, b = outs
+    assert a[1] is not None and a[1] == b[1]                       # the loss rides along
+    assert a[3].keys() == b[3].keys() and any(k.startswith("momentum.") for k in a[3])
+    for k in a[3]:
+        assert a[3][k] == b[3][k], k
+    assert a[4] == b[4] and abs(a[4] - 0.001) < 1e-12 and a[5] == b[5] == 1     # milestone 1 reached: lr 0.01 -> 0.001 on both
+
+
+def test_existing_window_lists_only_what_is_there(tmp_path):
+    from connect4_amd.generation import existing_window
+    for g in (3, 5):
+        os.makedirs(tmp_path / str(g))
+        (tmp_path / str(g) / "data.pth").write_bytes(b"x")
+    assert existing_window(str(tmp_path), 0) == [] and existing_window(str(tmp_path), 2) == []
+    assert existing_window(str(tmp_path), 6) == [5]                # window of gen 6 = 6,5,4 (data.py:66-72): 4 is missing, 3 is outside
+    assert existing_window(str(tmp_path), 5) == [3]                # window of gen 5 = 5,4,3: 5 is the generation being written

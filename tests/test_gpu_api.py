@@ -175,7 +175,7 @@ def test_fused_selfplay_kernel_equals_separate_kernels(monkeypatch):
     from connect4_amd.fused_net import FusedNet
     from connect4_amd.net import random_init_state_dict
     from connect4_amd.selfplay import SelfPlay
-    net = FusedNet(random_init_state_dict(seed=0))
+    net = FusedNet(random_init_state_dict(seed=0), precision="f16")   # (the workgroup-synchronous kernel serves the fp16 net only)
     cfg = MCTSConfig.self_play(48)
     out = []
     # separate kernels; then the three fused kernels (tree waves + network waves, wave-autonomous, workgroup-synchronous),
@@ -338,22 +338,25 @@ def test_end_to_end_net_driven_search_matches_reference():
     """The whole hot path on the GPU -- HIP tree walk + the policy/value net -- against the reference's
     NN-driven searches with data/example_net.pth (tests/golden/search_net.json, captured from the
     unmodified reference on CPU).
-      * fp32 PyTorch-ROCm net and the fused MFMA net in its reference-precision mode (fp16 hi+lo split,
-        fp32 accumulation): outputs differ from the CPU's by ~1e-6, far below the score gaps that decide an
-        argmax in these positions -> visit counts must be IDENTICAL, root value sums within 1e-4;
-      * fused net in fp16-storage mode (the fast default): outputs differ by up to 5e-3, so individual
+      * fp32 PyTorch-ROCm net and the fused MFMA net AS SHIPPED (FusedNet / make_selfplay_net with no precision
+        argument = the reference-precision mode: fp16 hi+lo split, fp32 accumulation): outputs differ from the CPU's
+        by ~1e-6, far below the score gaps that decide an argmax in these positions -> visit counts must be
+        IDENTICAL, root value sums within 1e-4;
+      * fused net in the opt-in fp16-storage mode (precision="f16"): outputs differ by up to 5e-3, so individual
         visit counts may move; stated tolerance: the visit distribution stays within 0.08 total variation
         and the chosen move is the same."""
     import torch
     from connect4_amd.board import Board
     from connect4_amd.evaluators import DeviceNetEvaluator
-    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.fused_net import FusedNet, make_selfplay_net
     from connect4_amd.mcts import MCTSConfig, search
     from connect4_amd.net import InferenceNet
     z = load_npz("net_golden.npz")
     sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w__")}
-    nets = {"fp32": InferenceNet(sd, device="cuda", dtype=torch.float32), "fused_f32x3": FusedNet(sd, precision="f32x3"),
-            "fused_f16": FusedNet(sd)}
+    default_net = make_selfplay_net(sd)
+    assert isinstance(default_net, FusedNet) and default_net.precision == "f32x3" and FusedNet(sd).precision == "f32x3"
+    nets = {"fp32": InferenceNet(sd, device="cuda", dtype=torch.float32), "fused_f32x3": default_net,
+            "fused_f16": FusedNet(sd, precision="f16")}
     cases = [c for c in load_json("search_net.json") if c["noise"] is None]
     assert len(cases) >= 7
     exact = {"fp32": 0, "fused_f32x3": 0}

@@ -5,6 +5,8 @@
 Bar: bit-exact for boards / visit counts / float64 value sums; net-driven searches are replayed
 through the captured float32 position table so they are bit-exact too.
 """
+import json
+
 import numpy as np
 import pytest
 
@@ -119,3 +121,40 @@ def test_selfplay_net_table(oracle):
     for g in load_json("selfplay_net.json"):
         ev = oracle.TableEvaluator(*table_from_npz(npz, g["name"]), prior_f32=True)
         check_game(oracle, g, ev)
+
+
+def test_replay_pool_plays_the_golden_selfplay_games(oracle):
+    """The lock-step replay pool (many tape-driven games behind one memoising evaluator table: what the full-size GPU
+    parity tests replay device games with) plays the reference's recorded self-play games: the golden net-driven games,
+    all at once, answered from their float32 position tables."""
+    npz = load_npz("selfplay_net_tables.npz")
+    games = load_json("selfplay_net.json")
+    cfgs = {json.dumps(g["config"], sort_keys=True) for g in games}
+    for cj in cfgs:
+        group = [g for g in games if json.dumps(g["config"], sort_keys=True) == cj]
+        cfg = oracle.make_config(**group[0]["config"])
+        noise = np.zeros((len(group), 42, 7))
+        u = np.full((len(group), 42), -1.0)
+        table = {}
+        for j, g in enumerate(group):
+            noise[j, :len(g["moves"])] = np.array(g["noise_tape"])
+            u[j, :len(g["uniforms"])] = g["uniforms"]
+            c0s, c1s, vs, ps = table_from_npz(npz, g["name"])
+            for a, b, v, p in zip(c0s, c1s, vs, ps):
+                table[(int(a), int(b))] = (np.float32(v), np.asarray(p, dtype=np.float32))
+        pool = oracle.ReplayPool(cfg, len(group), noise, u)
+        while True:
+            m = pool.collect()
+            if m == 0:
+                break
+            ans = [table[(int(pool.c0[k]), int(pool.c1[k]))] for k in range(m)]
+            pool.apply(m, np.array([a[0] for a in ans], dtype=np.float32), np.stack([a[1] for a in ans]))
+        for j, g in enumerate(group):
+            out = pool.game(j)
+            assert out["moves"] == g["moves"] and out["boards"] == [tuple(b) for b in g["boards"]]
+            assert out["result"] == RES[g["result"]] and out["policies"] == g["policies"]
+            for a, b in zip(out["values"], g["values"]):
+                assert (b is None and np.isnan(a)) or a == b
+        st = pool.stats()
+        assert st["hits"] > 0 and st["table_entries"] <= len(table)
+        pool.close()

@@ -15,12 +15,13 @@ def main():
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--wave", type=int, default=0, help="1: the wave-private forward (one position per wave)")
+    ap.add_argument("--precision", default="f16", choices=["f16", "f32x3"])
     args = ap.parse_args()
     from connect4_amd.fused_net import FusedNet
     from connect4_amd.net import InferenceNet, random_init_state_dict
     from connect4_amd.engine import board_planes
     sd = random_init_state_dict(seed=0)
-    net = FusedNet(sd)
+    net = FusedNet(sd, precision=args.precision)
     rng = np.random.RandomState(0)
     c0 = rng.randint(0, 2 ** 40, size=args.n).astype(np.uint64) & np.uint64(0x7EFDFBF7EFDF)
     c1 = (rng.randint(0, 2 ** 40, size=args.n).astype(np.uint64) & np.uint64(0x7EFDFBF7EFDF)) & ~c0
@@ -40,7 +41,7 @@ def main():
     torch.cuda.synchronize()
     us = a.elapsed_time(b) * 1000 / args.iters
     tf = 4.74e6 * args.n / (us * 1e-6) / 1e12
-    print("fused net: n=%d  %.1f us/forward  %.1f TFLOP/s (%.1f%% of 2.5 PF fp16 dense)" % (args.n, us, tf, tf / 25.0))
+    print("fused net (%s, wave=%d, active waves per CU %s): n=%d  %.1f us/forward  %.1f TFLOP/s (%.1f%% of 2.5 PF fp16 dense)" % (args.precision, int(wave), os.environ.get("C4_NET_WAVE_ACTIVE", "8"), args.n, us, tf, tf / 25.0))
     ref = InferenceNet(sd, device="cuda", dtype=torch.float32)
     planes = torch.from_numpy(board_planes(c0, c1)).cuda()
     rv, rp = ref(planes)
@@ -50,7 +51,7 @@ def main():
         out = (C.c_uint64 * 128)()
         rc = net._lib.c4_net_debug_stamps(net._h, out)
         st = np.array(list(out), dtype=np.int64).reshape(8, 16)
-        if wave:
+        if wave or args.precision != "f16":
             names = ["start", "stem"] + ["L%d" % i for i in range(6)] + ["tower_end", "heads", "mlp"]
             for w in range(8):
                 d = st[w, 1:11] - st[w, 0:10]

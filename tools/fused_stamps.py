@@ -17,7 +17,7 @@ from connect4_amd.selfplay import SelfPlay  # noqa: E402
 
 mi = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 budget = int(sys.argv[2]) if len(sys.argv) > 2 else 80000
-net = FusedNet(random_init_state_dict(seed=0))
+net = FusedNet(random_init_state_dict(seed=0), precision=os.environ.get("C4_NET_PRECISION", "f32x3"))
 sp = SelfPlay(net, 4096, MCTSConfig.self_play(800), seed=0, use_graph=False, fused_loop=True, steps_per_launch=32,
               max_inner_iters=mi, time_budget_cycles=budget)
 sp.run_steps(3200)

@@ -15,7 +15,7 @@ from connect4_amd.net import random_init_state_dict  # noqa: E402
 from connect4_amd.selfplay import SelfPlay  # noqa: E402
 
 slots = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-net = FusedNet(random_init_state_dict(seed=0))
+net = FusedNet(random_init_state_dict(seed=0), precision=os.environ.get("C4_NET_PRECISION", "f32x3"))
 sp = SelfPlay(net, slots, MCTSConfig.self_play(800), seed=0, use_graph=False, fused_loop=True, steps_per_launch=256, max_inner_iters=32)
 sp.run_steps(256 * 150)
 sp.synchronize()

@@ -15,8 +15,8 @@ from connect4_amd.net import random_init_state_dict  # noqa: E402
 from connect4_amd.selfplay import SelfPlay  # noqa: E402
 
 slots = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-prec = os.environ.get("C4_NET_PRECISION", "f16")   # f16 | f32x3
-tw = int(os.environ.get("C4_SPLIT_TW", "4" if prec == "f16" else "2"))
+prec = os.environ.get("C4_NET_PRECISION", "f32x3")   # f32x3 (the default net) | f16
+tw = int(os.environ.get("C4_SPLIT_TW", "4"))
 net = FusedNet(random_init_state_dict(seed=0), precision=prec)
 sp = SelfPlay(net, slots, MCTSConfig.self_play(800), seed=0, use_graph=False, fused_loop=True, steps_per_launch=64, max_inner_iters=32)
 sp.run_steps(6400)

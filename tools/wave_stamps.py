@@ -16,7 +16,7 @@ from connect4_amd.selfplay import SelfPlay  # noqa: E402
 
 slots = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 mi = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-net = FusedNet(random_init_state_dict(seed=0))
+net = FusedNet(random_init_state_dict(seed=0), precision=os.environ.get("C4_NET_PRECISION", "f32x3"))
 sp = SelfPlay(net, slots, MCTSConfig.self_play(800), seed=0, use_graph=False, fused_loop=True, steps_per_launch=64,
               max_inner_iters=mi)
 sp.run_steps(int(sys.argv[3]) if len(sys.argv) > 3 else 6400)

@@ -1709,7 +1709,7 @@ __device__ __forceinline__ void sanitise_answer(float *s_val, float *s_pri, int 
 // ------------------------------------------------------------------------------------------
 template <int TS, int MODE, int TW = 4>
 __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(const Dev *d_dev, c4net::NetDev nd, float *__restrict__ values,
-                                                                            float *__restrict__ priors, int n_steps)
+                                                                            float *__restrict__ priors, int n_steps, int spread)
 {
     using namespace c4net;
     const_dev &d = *(const_dev *)d_dev;
@@ -1737,10 +1737,14 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
     __shared__ uint32_t s_req[TS];     // REQ_* of the slot's leaf
     __shared__ uint32_t s_simd[4];     // waves seen per SIMD (role assignment)
     __shared__ uint32_t s_tree_done;   // tree waves past the deadline
-    const int slot0 = blockIdx.x * TS;
+    // slot p of this workgroup.  Dense: TS consecutive slots per workgroup.  Spread (fewer slots than TS per CU): slot
+    // blockIdx.x + p * gridDim.x, so that a batch smaller than TS x CUs still puts work on EVERY CU (1,200 games -- the
+    // reference's generation, config.py:64 -- are 4-5 slots on each of 256 CUs instead of 16 slots on 75 of them).
+    const int wg_first = (spread & 1) ? (int)blockIdx.x : (int)blockIdx.x * TS, wg_stride = (spread & 1) ? (int)gridDim.x : 1;
+    auto gslot = [&](int p) -> int { return wg_first + p * wg_stride; };
     // ---- launch prologue: slot states, pending answers and the MLP tables, global -> LDS
     if (threadIdx.x < TS) {
-        const int p = threadIdx.x, g = slot0 + p;
+        const int p = threadIdx.x, g = gslot(p);
         SlotMem m = {};
         m.flags = SlotMem::pack(SLOT_PARKED, 0, 0);
         if (g < d.G) {
@@ -1758,9 +1762,10 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
     if (threadIdx.x == 0) s_tree_done = 0;
     for (int i = threadIdx.x; i < TS * 8; i += NTHREADS) {   // answers of the previous launch
         const int p = i >> 3, k = i & 7;
-        const bool ok = slot0 + p < d.G;
-        if (k == 7) s_val[p] = ok ? values[slot0 + p] : 0.0f;
-        else s_pri[p * 7 + k] = ok ? priors[(size_t)(slot0 + p) * 7 + k] : 0.0f;
+        const int g = gslot(p);
+        const bool ok = g < d.G;
+        if (k == 7) s_val[p] = ok ? values[g] : 0.0f;
+        else s_pri[p * 7 + k] = ok ? priors[(size_t)g * 7 + k] : 0.0f;
     }
     for (int i = threadIdx.x; i < MLP_F4; i += NTHREADS) mlp[i] = nd.mlp[i];
     stage_bias_lds(nd, s_bias);
@@ -1768,9 +1773,23 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
     if (threadIdx.x < 64) build_tab16<MODE == NETMODE_F64 ? CS64 : CS16>(s_tab16, threadIdx.x);
     for (int i = threadIdx.x; i < TS * MAX_DEPTH; i += NTHREADS) {   // paths of leaves pending from the previous launch
         const int p = i / MAX_DEPTH, k = i - p * MAX_DEPTH;
-        if (slot0 + p < d.G) s_path[p][k] = d.path[(size_t)(slot0 + p) * MAX_DEPTH + k];
+        if (gslot(p) < d.G) s_path[p][k] = d.path[(size_t)gslot(p) * MAX_DEPTH + k];
     }
     __syncthreads();
+    // Answers carried over from the previous launch were written by whatever ran last -- a network wave of this kernel (already
+    // finite) or c4_net_forward / a host evaluator between c4_step launches (include/c4_engine.h: the launches are
+    // interchangeable) -- and the tree waves below apply answers without a check of their own: make them finite here.
+    if (C4_NET_SANITISES && threadIdx.x < TS && smem[threadIdx.x].has_leaf()) {
+        const int p = threadIdx.x;
+        bool bad = false;
+        const float v = s_val[p];
+        if (!(v >= 0.0f && v <= 1.0f)) { s_val[p] = 0.5f; bad = true; }
+        for (int k = 0; k < 7; ++k) {
+            const float q = s_pri[p * 7 + k];
+            if (!(q >= 0.0f && q <= 3.0e38f)) { s_pri[p * 7 + k] = 0.0f; bad = true; }
+        }
+        if (bad) atomicAdd(&s_stats[offsetof(SlotStats, bad_evals) / sizeof(uint64_t)], 1u);
+    }
     // ---- roles: HW_ID.SIMD_ID says where the wave runs; the first wave to register on a SIMD walks trees
     const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3;   // HW_REG_HW_ID bits [5:4]
     int rank = 0;
@@ -1783,8 +1802,13 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
     // busier half there): SIMDs 0..2 carry a tree wave and a network wave, SIMD 3 two network waves.
     const bool even = (TW == 4 || TW == 3) && s_simd[0] == 2 && s_simd[1] == 2 && s_simd[2] == 2 && s_simd[3] == 2;
     const int wv = threadIdx.x >> 6;
-    const bool is_tree = even ? (rank == 0 && simd < TW) : wv < TW;
-    const int role_idx = even ? (is_tree ? simd : (TW == 4 ? simd : (rank == 0 ? 4 : simd))) : (wv < TW ? wv : wv - TW);
+    // spread >> 1 (tuning aid C4_SPLIT_SEG=1, TW == 4): SEGREGATED roles -- both waves of SIMDs 0 and 1 walk trees, both waves of
+    // SIMDs 2 and 3 run the network (an MFMA holds its SIMD's vector issue for half its cycles: a tree wave next to a busy
+    // network wave loses those issue slots)
+    const bool seg = TW == 4 && even && (spread & 2);
+    const bool is_tree = seg ? simd < 2 : (even ? (rank == 0 && simd < TW) : wv < TW);
+    const int role_idx = seg ? ((simd & 1) * 2 + rank)
+                             : (even ? (is_tree ? simd : (TW == 4 ? simd : (rank == 0 ? 4 : simd))) : (wv < TW ? wv : wv - TW));
     const unsigned long long t_launch = __builtin_amdgcn_s_memtime();
     const unsigned long long quantum = (unsigned long long)n_steps * (unsigned long long)(d.time_budget > 0 ? d.time_budget : 80000);
     unsigned long long t_busy = 0, n_pass = 0;   // diagnostic (C4_TREE_STAMPS=1)
@@ -1807,7 +1831,7 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
                 continue;
             }
             if (grp < SPW && sl < TS)
-                tree_step<C4_EVAL_EXTERNAL_F32, false, true, true, true, const_dev, true>(d, slot0 + sl, lane, sl, s_path, s_l1, s_val, s_pri, nullptr,
+                tree_step<C4_EVAL_EXTERNAL_F32, false, true, true, true, const_dev, true>(d, wg_first + sl * wg_stride, lane, sl, s_path, s_l1, s_val, s_pri, nullptr,
                                                                                           nullptr, &smem[sl], sl, s_stats, t_launch + quantum,
                                                                                           &s_req[sl]);
             lds_fence();
@@ -1912,22 +1936,23 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
     // ---- launch epilogue: LDS -> global
     for (int i = threadIdx.x; i < TS * MAX_DEPTH; i += NTHREADS) {   // paths of the leaves whose answers wait for the next launch
         const int p = i / MAX_DEPTH, k = i - p * MAX_DEPTH;
-        if (slot0 + p < d.G && smem[p].has_leaf()) d.path[(size_t)(slot0 + p) * MAX_DEPTH + k] = s_path[p][k];
+        if (gslot(p) < d.G && smem[p].has_leaf()) d.path[(size_t)gslot(p) * MAX_DEPTH + k] = s_path[p][k];
     }
-    if (threadIdx.x < TS && slot0 + threadIdx.x < d.G) {
-        const int p = threadIdx.x, g = slot0 + p;
+    if (threadIdx.x < TS && gslot(threadIdx.x) < d.G) {
+        const int p = threadIdx.x, g = gslot(p);
         const SlotMem m = smem[p];
         d.root_c0[g] = m.root0; d.root_c1[g] = m.root1; d.leaf_c0[g] = m.leaf0; d.leaf_c1[g] = m.leaf1;
         d.game_id[g] = m.gid; d.sims_done[g] = m.sims; d.n_alloc[g] = m.nalloc; d.pending[g] = m.pend;
         d.pending_depth[g] = m.pdepth; d.pending_info[g] = m.pinfo; d.need_root[g] = m.need_root();
         d.ply[g] = m.ply; d.state[g] = m.state(); d.has_leaf[g] = m.has_leaf() ? 1 : 0;
     }
-    if (threadIdx.x < N_STATS) d.stats[(size_t)slot0 * N_STATS + threadIdx.x] += s_stats[threadIdx.x];
+    if (threadIdx.x < N_STATS && wg_first < d.G) d.stats[(size_t)wg_first * N_STATS + threadIdx.x] += s_stats[threadIdx.x];   // the row of the workgroup's first slot
     for (int i = threadIdx.x; i < TS * 8; i += NTHREADS) {
         const int p = i >> 3, k = i & 7;
-        if (slot0 + p < d.G) {
-            if (k == 7) values[slot0 + p] = s_val[p];
-            else priors[(size_t)(slot0 + p) * 7 + k] = s_pri[p * 7 + k];
+        const int g = gslot(p);
+        if (g < d.G) {
+            if (k == 7) values[g] = s_val[p];
+            else priors[(size_t)g * 7 + k] = s_pri[p * 7 + k];
         }
     }
 }
@@ -2242,7 +2267,10 @@ struct c4_engine {
     int64_t *export_scratch;              // device: [0] games, [1] positions of the last export, [2..] per-game offsets
     int64_t launches;
     int fused_slots;      // slots per workgroup of the fused self-play kernel (16 or 32)
+    int cus;              // compute units of the device
+    int pack_dense;       // C4_FUSED_PACK=dense: consecutive slots per workgroup even when that leaves CUs idle (tests of ragged workgroups)
     int fused_wave;       // 1: wave-autonomous fused kernel (c4_selfplay_wave_kernel); 2: tree waves + network waves (c4_selfplay_split_kernel)
+    int split_seg;        // tuning aid (C4_SPLIT_SEG=1): segregated roles, see c4_selfplay_split_kernel
     int split_tw;         // tuning aid (C4_SPLIT_TW=2|4): tree waves of the split kernel at 16 slots per workgroup; 0 = by net mode
     int tape_games;
     double *tape_noise, *tape_u;
@@ -2366,11 +2394,18 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
-        e->fused_slots = ((cfg->n_slots + 31) / 32 >= cus) ? 32 : 16;
+        e->cus = cus;
+        // 16 slots per workgroup while that fills the chip once (one workgroup per CU: its LDS), 32 beyond; a batch that does
+        // not fill TS x CUs slots is SPREAD over all CUs by the split kernel (see c4_selfplay_steps)
+        e->fused_slots = (cfg->n_slots > 16 * cus) ? 32 : 16;
+        e->pack_dense = 0;
+        if (const char *pk = getenv("C4_FUSED_PACK")) e->pack_dense = strcmp(pk, "dense") == 0;
         e->fused_wave = 2;   // tree waves + network waves; C4_FUSED_MODE=wave / block select the wave-autonomous / workgroup-synchronous kernels
         if (const char *fm = getenv("C4_FUSED_MODE")) e->fused_wave = strcmp(fm, "block") == 0 ? 0 : (strcmp(fm, "wave") == 0 ? 1 : 2);
         e->split_tw = 0;     // 0: chosen by the net's mode
         if (const char *tw = getenv("C4_SPLIT_TW")) e->split_tw = atoi(tw);
+        e->split_seg = 0;
+        if (const char *sg = getenv("C4_SPLIT_SEG")) e->split_seg = atoi(sg);
         if (const char *fs = getenv("C4_FUSED_SLOTS")) {   // tuning aid: force 16 or 32
             const int v = atoi(fs);
             if (v == 16 || v == 32) e->fused_slots = v;
@@ -2612,7 +2647,12 @@ int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *prior
         // 2 tree waves); the 64-filter forward is slow enough to want more network waves: 2 tree waves of 8 slots and 6
         // network waves at 16 slots per CU (111 against 104 M)
         const int tw = e->split_tw ? e->split_tw : (nd.mode == c4net::NETMODE_F64 ? 2 : 4);
-#define C4_LAUNCH_SPLIT(TSV, MODE, TWV) hipLaunchKernelGGL((c4_selfplay_split_kernel<TSV, MODE, TWV>), (TSV == 32 ? g32 : g16), blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps)
+        // the split kernel spreads a batch that would leave CUs without a workgroup over all of them (slot = workgroup + p x workgroups)
+        const int dense_wgs = (e->d.G + e->fused_slots - 1) / e->fused_slots;
+        const int spread = (!e->pack_dense && dense_wgs < e->cus && e->d.G > dense_wgs) ? 1 : 0;
+        const dim3 gsp(spread ? std::min(e->cus, e->d.G) : dense_wgs);
+        const int kflags = spread | (e->split_seg ? 2 : 0);
+#define C4_LAUNCH_SPLIT(TSV, MODE, TWV) hipLaunchKernelGGL((c4_selfplay_split_kernel<TSV, MODE, TWV>), gsp, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps, kflags)
 #define C4_LAUNCH_WAVE(MODE)                                                                                                       \
     do {                                                                                                                           \
         if (e->fused_wave == 2) {                                                                                                  \

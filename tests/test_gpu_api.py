@@ -180,6 +180,7 @@ def test_fused_selfplay_kernel_equals_separate_kernels(monkeypatch):
     out = []
     # separate kernels; then the three fused kernels (tree waves + network waves, wave-autonomous, workgroup-synchronous),
     # each with 16 and 32 slots per workgroup (72 slots: ragged last workgroup)
+    monkeypatch.setenv("C4_FUSED_PACK", "dense")    # 72 slots in 16- / 32-slot workgroups (the default would spread them one per CU)
     for mode, fused in (("wave", 0), ("split", 16), ("split", 32), ("wave", 16), ("wave", 32), ("block", 16), ("block", 32)):
         monkeypatch.setenv("C4_FUSED_MODE", mode)
         monkeypatch.setenv("C4_FUSED_SLOTS", str(fused or 16))
@@ -216,6 +217,7 @@ def test_split_kernel_edge_cases_play_the_same_games(monkeypatch, cache_bits):
     net = FusedNet(random_init_state_dict(seed=0))
     cfg = MCTSConfig.self_play(32)
     out = []
+    monkeypatch.setenv("C4_FUSED_PACK", "dense")    # one full and one ragged workgroup
     for mode in ("wave", "split"):
         monkeypatch.setenv("C4_FUSED_MODE", mode)
         sp = SelfPlay(net, 19, cfg, seed=5, games_target=12, record_capacity_games=32, use_graph=False,
@@ -253,6 +255,7 @@ def test_split_kernel_other_nets_play_the_same_games(monkeypatch, kind):
         net = FusedNet(random_init_state_dict(seed=0), precision="f32x3")
     cfg = MCTSConfig.self_play(32)
     out = []
+    monkeypatch.setenv("C4_FUSED_PACK", "dense")
     for mode, fused in (("wave", False), ("wave", True), ("split", True)):
         monkeypatch.setenv("C4_FUSED_MODE", mode)
         sp = SelfPlay(net, 40, cfg, seed=21, games_target=48, record_capacity_games=64, use_graph=False,
@@ -268,6 +271,37 @@ def test_split_kernel_other_nets_play_the_same_games(monkeypatch, kind):
         out.append(([(g.game_id, g.moves, g.result.value, g.values, [list(p) for p in g.priors]) for g in games],
                     {k: st[k] for k in ("simulations", "expansions", "moves", "games_finished", "terminal_sims", "leaf_evals")}))
     assert out[0] == out[1] == out[2]
+    net.close()
+
+
+@pytest.mark.parametrize("precision", ["f32x3", "f16"])
+def test_spread_workgroups_play_the_same_games(monkeypatch, precision):
+    """A batch that does not fill 16 slots on every CU is spread over all CUs by the split kernel (slot = workgroup + p x
+    workgroups: 1,200 games -- the reference's generation, config.py:64 -- are 4-5 slots on each of 256 CUs instead of 16
+    slots on 75 of them).  Same seed => the games of the dense packing, id by id; also with three tree waves."""
+    from connect4_amd.config import MCTSConfig
+    from connect4_amd.fused_net import FusedNet
+    from connect4_amd.net import random_init_state_dict
+    from connect4_amd.selfplay import SelfPlay
+    net = FusedNet(random_init_state_dict(seed=0), precision=precision)
+    cfg = MCTSConfig.self_play(32)
+    out = []
+    for pack, tw in (("dense", "4"), ("spread", "4"), ("spread", "3"), ("dense", "3")):
+        monkeypatch.setenv("C4_FUSED_PACK", pack)
+        monkeypatch.setenv("C4_SPLIT_TW", tw)
+        sp = SelfPlay(net, 600, cfg, seed=9, games_target=700, record_capacity_games=700, use_graph=False,
+                      fused_loop=True, steps_per_launch=8)
+        for _ in range(2000):
+            sp.run_steps(32)
+            if sp.stats()["active_slots"] == 0:
+                break
+        games = sorted(sp.drain(), key=lambda g: g.game_id)
+        st = sp.stats()
+        sp.close()
+        assert len(games) == 700 and st["bad_evals"] == 0 and st["dropped_games"] == 0
+        out.append(([(g.game_id, g.moves, g.result.value, g.values, [list(p) for p in g.priors]) for g in games],
+                    {k: st[k] for k in ("simulations", "expansions", "moves", "games_finished", "terminal_sims", "leaf_evals")}))
+    assert out[0] == out[1] == out[2] == out[3]
     net.close()
 
 
@@ -295,10 +329,31 @@ def test_fused_kernels_contain_a_net_that_answers_nan(monkeypatch, mode):
     st = sp.stats()
     games = sp.drain()
     sp.close()
-    net.close()
     assert st["bad_evals"] > 0 and len(games) == 24
     for g in games:
         assert 7 <= len(g.moves) <= 42
+    # ... and launch by launch mixed with the separate kernels (include/c4_engine.h: the launches are interchangeable): c4_step
+    # emits leaves, c4_net_forward writes NaN answers into the GLOBAL buffers, and the fused kernel that follows picks those
+    # leaves up as "answered" -- answers no network wave of that kernel has looked at (the split kernel's tree
+    # waves carry no check of their own, so its prologue has to make carried-over answers finite)
+    sp = SelfPlay(net, 24, MCTSConfig.self_play(24), seed=3, games_target=24, record_capacity_games=32, use_graph=False,
+                  fused_loop=False, steps_per_launch=8, max_inner_iters=3)
+    for rnd in range(4000):
+        sp._fused_loop = False
+        sp.run_steps(1)                # c4_step + c4_net_forward: every slot with a leaf now holds a NaN answer in global memory
+        sp._fused_loop = True
+        sp.run_steps(2)                # the fused kernel applies them
+        if rnd % 16 == 15 and sp.stats()["active_slots"] == 0:
+            break
+    st = sp.stats()
+    games = sp.drain()
+    sp.close()
+    net.close()
+    assert st["active_slots"] == 0 and st["bad_evals"] > 0 and len(games) == 24
+    for g in games:
+        assert 7 <= len(g.moves) <= 42 and all(0 <= m < 7 for m in g.moves)
+        for pol in g.priors:
+            assert all(x == x for x in pol) and abs(sum(pol) - 1.0) < 1e-9      # no NaN reached a policy
 
 
 def test_mini_generation_selfplay_train_reload(tmp_path):

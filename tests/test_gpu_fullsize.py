@@ -1,13 +1,19 @@
-"""BASELINE shapes at FULL size under -m gpu.
+"""BASELINE shapes at FULL size under -m gpu, on the PRODUCTION path: c4_selfplay_split_kernel (tree waves + network waves)
++ the evaluation cache + the fused MFMA net, with injected RNG tapes; then a sample of >= 256 finished games (64 at 3200
+simulations) is replayed move for move on the CPU oracle (its lock-step replay pool, OpenMP over games), whose memoising
+evaluator is answered with what the DEVICE's evaluation cache holds for each position (c4_eval_cache_lookup).  Moves,
+float64 values, float64 policies and results must be IDENTICAL.  Reference: mcts.py:94-121, training_game.py:8-19,
+evaluators.py:9-25.
 
-(i)  configs[1]: 4096 games x 800 simulations on the PRODUCTION path -- c4_selfplay_split_kernel + the 2^28-entry
-     evaluation cache + the fused MFMA net -- with injected RNG tapes, then a sample of the finished games is
-     replayed move for move on the CPU oracle, whose evaluator answers with what the device's evaluation cache
-     holds for each position (c4_eval_cache_lookup; FusedNet for a position the direct-mapped table has since
-     evicted).  Moves, float64 values, float64 policies and results must be IDENTICAL.
-     Reference: mcts.py:94-121, training_game.py:8-19.
-(ii) configs[3]: 8192 searches x 3200 simulations (deep trees) with the in-kernel centre evaluator, a sample
-     against the oracle: visit counts and float64 value sums identical.
+(i)   configs[1]: 4096 games x 800 simulations, the shipped default net (reference precision, f32x3) and the opt-in fp16 net;
+(ii)  configs[2]'s per-GPU share: 8192 games x 800 simulations (32 slots per workgroup: eight slots per tree wave; the fp16
+      net's network waves take two requests per pass there);
+(iii) configs[3]: 8192 games x 3200 simulations (deep trees), reference-precision net;
+(iv)  configs[3] search-only: 8192 searches x 3200 simulations with the in-kernel centre evaluator against the oracle.
+
+Positions the direct-mapped table has lost to a later collision (2^28..2^29 entries at a few per cent load: a few per cent
+of the positions, bounded below) are RE-EVALUATED BY THE NET for the oracle -- for those the replay checks the engine
+against the net's answer, not against the stored one.
 """
 import numpy as np
 import pytest
@@ -15,45 +21,60 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_config1_4096_games_800_sims_fused_kernel_vs_oracle(oracle):
+def play_and_replay(oracle, G, S, precision, n_replay, seed, lost_share_max):
     from connect4_amd import _lib as L
     from connect4_amd.config import MCTSConfig
     from connect4_amd.fused_net import FusedNet
     from connect4_amd.net import random_init_state_dict
     from connect4_amd.selfplay import SelfPlay
-    G, S = 4096, 800
+    from oracle.replay import oracle_config, random_tapes, replay_games_bulk
     cfg = MCTSConfig.self_play(S)
-    net = FusedNet(random_init_state_dict(seed=0))
+    net = FusedNet(random_init_state_dict(seed=0), precision=precision)
+    assert net.precision == ("f32x3" if precision is None else precision)
     sp = SelfPlay(net, G, cfg, seed=0, games_target=G, record_capacity_games=G, use_graph=False, fused_loop=True,
-                  steps_per_launch=128, rng_mode=L.RNG_TAPE)
-    from oracle.replay import oracle_config, random_tapes, replay_game
-    noise, u = random_tapes(G, cfg.root_dirichlet_alpha, seed=123)
-    sp.engine.set_tapes(noise, u)
-    sp.engine.reset()
-    for _ in range(2000):
-        sp.run_steps(256)
-        st = sp.stats()
-        if st["active_slots"] == 0:
-            break
-    assert st["active_slots"] == 0 and st["games_finished"] == G and st["dropped_games"] == 0 and st["bad_evals"] == 0
-    assert st["simulations"] == S * st["moves"]
-    recs = sp.engine.drain_games()
-    assert len(recs) == G and [r.game_id for r in recs] == list(range(G))
-    lengths = np.array([r.length for r in recs])
-    rng = np.random.RandomState(5)
-    sample = set(rng.choice(G, size=12, replace=False).tolist())
-    sample |= {int(np.argmax(lengths)), int(np.argmin(lengths))}          # the longest and the shortest game too
-    ocfg = oracle_config(cfg)
-    lookups = evicted = 0
-    for gid in sorted(sample):
-        s = replay_game(ocfg, sp.engine, net, recs[gid], noise[gid], u[gid])
-        lookups += s["lookups"]
-        evicted += s["evicted"]
-    # the table really is what answered: 2^28 direct-mapped entries at ~7 % load lose about that share of the
-    # positions to collisions (measured 5.2 %); those are re-evaluated by the same deterministic net
-    assert lookups > 1000 and evicted <= 0.10 * lookups
-    sp.close()
-    net.close()
+                  steps_per_launch=128, max_inner_iters=32, rng_mode=L.RNG_TAPE)
+    try:
+        noise, u = random_tapes(G, cfg.root_dirichlet_alpha, seed=seed)
+        sp.engine.set_tapes(noise, u)
+        sp.engine.reset()
+        for _ in range(4000):
+            sp.run_steps(256)
+            st = sp.stats()
+            if st["active_slots"] == 0:
+                break
+        assert st["active_slots"] == 0 and st["games_finished"] == G and st["dropped_games"] == 0 and st["bad_evals"] == 0
+        assert st["simulations"] == S * st["moves"]
+        recs = sp.engine.drain_games()
+        assert len(recs) == G and [r.game_id for r in recs] == list(range(G))
+        lengths = np.array([r.length for r in recs])
+        rng = np.random.RandomState(5)
+        sample = set(rng.choice(G, size=n_replay - 2, replace=False).tolist())
+        sample |= {int(np.argmax(lengths)), int(np.argmin(lengths))}          # the longest and the shortest game too
+        res = replay_games_bulk(oracle_config(cfg), sp.engine, net, [recs[g] for g in sorted(sample)], noise, u, threads=16)
+        print("%d x %d %s: %d games replayed on the oracle, %d positions asked in %d rounds, %d lost by the table (re-evaluated by the net)"
+              % (G, S, net.precision, res["games"], res["positions_asked"], res["rounds"], res["lost_by_the_table"]))
+        # the table really is what answered
+        assert res["games"] >= n_replay - 2 and res["positions_asked"] > 1000
+        assert res["lost_by_the_table"] <= lost_share_max * res["positions_asked"]
+        return st
+    finally:
+        sp.close()
+        net.close()
+
+
+@pytest.mark.parametrize("precision", [None, "f16"])
+def test_config1_4096_games_800_sims_split_kernel_vs_oracle(oracle, precision):
+    play_and_replay(oracle, 4096, 800, precision, n_replay=256, seed=123, lost_share_max=0.10)
+
+
+@pytest.mark.parametrize("precision", [None, "f16"])
+def test_config2_share_8192_games_800_sims_split_kernel_vs_oracle(oracle, precision):
+    st = play_and_replay(oracle, 8192, 800, precision, n_replay=256, seed=321, lost_share_max=0.15)
+    assert st["eval_cache_hits"] > 0
+
+
+def test_config3_8192_games_3200_sims_split_kernel_vs_oracle(oracle):
+    play_and_replay(oracle, 8192, 3200, None, n_replay=64, seed=77, lost_share_max=0.25)
 
 
 def test_config4_8192_searches_3200_sims_vs_oracle(oracle):

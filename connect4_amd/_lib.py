@@ -112,6 +112,7 @@ SIGNATURES = {
     "c4_board_centre_value": (C.c_int, [C.c_int, _u64p, _u64p, C.c_int32, _f64p]),
     "c4_debug_stamps": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
     "c4_debug_fused_net_stamps": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
+    "c4_debug_latency_stamps": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
     "c4_net_create": (C.c_int, [C.c_int, _P(NetDesc), _P(C.c_void_p)]),
     "c4_net_destroy": (C.c_int, [C.c_void_p]),
     "c4_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),

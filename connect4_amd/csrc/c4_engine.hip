@@ -665,7 +665,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                                           const void *__restrict__ priors_in, void *__restrict__ planes_out,
                                           uint64_t *leaf_out, SlotMem *sm = nullptr, const int ai_lds = 0,
                                           uint32_t *wg_stats = nullptr, const unsigned long long deadline = 0,
-                                          uint32_t *req = nullptr)
+                                          uint32_t *req = nullptr, const int diag_stride = 0)
 {
     static_assert(!SPLIT || (WAVE_SYNC && LDS_STATE && PATH_KEPT), "the split kernel keeps slot states and paths in LDS");
     if (leaf_out && lane < 2) leaf_out[lane] = 0;
@@ -780,6 +780,12 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                 if ((long long)(__builtin_amdgcn_s_memtime() - deadline) > 0) { has_leaf = 1; break; }
 #endif
                 if (lds_ld(req) != REQ_ANSWERED) continue;
+#if C4_SPLIT_PHASES
+                if (lane == 0) {   // diagnostic: answered -> picked up, in units of 64 cycles
+                    uint32_t *sums = req - ai + 3 * diag_stride;
+                    atomicAdd(&sums[2], ((uint32_t)__builtin_amdgcn_s_memtime() - lds_ld(req + 2 * diag_stride)) >> 6);
+                }
+#endif
                 ev_value = (double)lds_ldf((const float *)values_in + ai);
                 ev_prior = lane < 7 ? (double)lds_ldf((const float *)priors_in + (size_t)ai * 7 + lane) : 0.0;
                 if (lane == 0) lds_st(req, REQ_IDLE);
@@ -938,6 +944,9 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                 if (lane == 0) {
                     lds_st64(&sm->leaf0, leaf0);
                     lds_st64(&sm->leaf1, leaf1);
+#if C4_SPLIT_PHASES
+                    lds_st(req + diag_stride, (uint32_t)__builtin_amdgcn_s_memtime());   // diagnostic: when the request was posted
+#endif
                     lds_st(req, REQ_POSTED);   // LDS executes a wave's accesses in order: the board is there before the word says so
                 }
                 waiting = true;
@@ -1325,6 +1334,9 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             if (lane == 0) {
                 lds_st64(&sm->leaf0, leaf0);
                 lds_st64(&sm->leaf1, leaf1);
+#if C4_SPLIT_PHASES
+                lds_st(req + diag_stride, (uint32_t)__builtin_amdgcn_s_memtime());
+#endif
                 lds_st(req, REQ_POSTED);   // LDS executes a wave's accesses in order: the board is there before the word says so
             }
             waiting = true;
@@ -1722,7 +1734,14 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
     constexpr int WBUF = WaveBuf<MODE>::HALVES * (PAIRS ? 2 : 1);
     // speculative evaluation by network waves that have nothing else to do (4096 games: +4.3 %, f32x3 +1.2 %, 8192 games +0.2 %;
     // 64 filters -1.5 %: its network waves are never idle and the check is not free)
-    constexpr bool SPECULATE = C4_SPECULATE && MODE != NETMODE_F64;
+    // A speculative pass occupies its wave for a whole forward, and a real request that arrives meanwhile waits.  With the fp16 net
+    // (17 k cycles per pass, network waves busy half the time) that is rare and speculation is worth +4 %; with the reference-precision
+    // net (34 k cycles per pass, network waves busy 80 % with real requests alone) it COSTS 3.5 % (r03 A/B, profiles/r03_ab_speculation.json:
+    // always 235 M, only while one / two / three other network waves are idle 236 / 239 / 241 M, never 244 M): off there, as for
+    // 64 filters.
+    constexpr bool SPECULATE = C4_SPECULATE && MODE == NETMODE_F32_F16;
+    // (two network waves per position -- the forward split by cout tile, shared planes, a flag handshake per layer -- was built,
+    // bit-identical, and measured: latency -28 %, but 43 k instead of 31 k wave-cycles per evaluation; -17 %.  profiles/r03_ab_pair_split_and_roles.json)
     __shared__ __attribute__((aligned(16))) _Float16 act[NW][WBUF];   // planes of the network waves
     __shared__ __attribute__((aligned(16))) float4 mlp[MLP_F4];
     __shared__ SlotMem smem[TS];
@@ -1734,13 +1753,13 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
     __shared__ __attribute__((aligned(16))) half8 s_w0[W0Lds<MODE>::FRAGS];  // reference-precision forward: the fragments a pass needs first
     __shared__ __attribute__((aligned(16))) PathEntry s_path[TS][MAX_DEPTH];   // every slot's descent path, for the whole launch
     __shared__ __attribute__((aligned(16))) Rec s_l1[TS][GROUP];               // every slot's root block
-    __shared__ uint32_t s_req[TS];     // REQ_* of the slot's leaf
+    __shared__ uint32_t s_req[C4_SPLIT_PHASES ? 3 * TS + 4 : TS];     // REQ_* of the slot's leaf (diagnostic build: + post / answer times, latency sums)
     __shared__ uint32_t s_simd[4];     // waves seen per SIMD (role assignment)
     __shared__ uint32_t s_tree_done;   // tree waves past the deadline
     // slot p of this workgroup.  Dense: TS consecutive slots per workgroup.  Spread (fewer slots than TS per CU): slot
     // blockIdx.x + p * gridDim.x, so that a batch smaller than TS x CUs still puts work on EVERY CU (1,200 games -- the
     // reference's generation, config.py:64 -- are 4-5 slots on each of 256 CUs instead of 16 slots on 75 of them).
-    const int wg_first = (spread & 1) ? (int)blockIdx.x : (int)blockIdx.x * TS, wg_stride = (spread & 1) ? (int)gridDim.x : 1;
+    const int wg_first = spread ? (int)blockIdx.x : (int)blockIdx.x * TS, wg_stride = spread ? (int)gridDim.x : 1;
     auto gslot = [&](int p) -> int { return wg_first + p * wg_stride; };
     // ---- launch prologue: slot states, pending answers and the MLP tables, global -> LDS
     if (threadIdx.x < TS) {
@@ -1759,6 +1778,9 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
     }
     if (threadIdx.x < N_STATS) s_stats[threadIdx.x] = 0;
     if (threadIdx.x < 4) s_simd[threadIdx.x] = 0;
+#if C4_SPLIT_PHASES
+    if (threadIdx.x < 4) s_req[3 * TS + threadIdx.x] = 0;
+#endif
     if (threadIdx.x == 0) s_tree_done = 0;
     for (int i = threadIdx.x; i < TS * 8; i += NTHREADS) {   // answers of the previous launch
         const int p = i >> 3, k = i & 7;
@@ -1802,13 +1824,11 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
     // busier half there): SIMDs 0..2 carry a tree wave and a network wave, SIMD 3 two network waves.
     const bool even = (TW == 4 || TW == 3) && s_simd[0] == 2 && s_simd[1] == 2 && s_simd[2] == 2 && s_simd[3] == 2;
     const int wv = threadIdx.x >> 6;
-    // spread >> 1 (tuning aid C4_SPLIT_SEG=1, TW == 4): SEGREGATED roles -- both waves of SIMDs 0 and 1 walk trees, both waves of
-    // SIMDs 2 and 3 run the network (an MFMA holds its SIMD's vector issue for half its cycles: a tree wave next to a busy
-    // network wave loses those issue slots)
-    const bool seg = TW == 4 && even && (spread & 2);
-    const bool is_tree = seg ? simd < 2 : (even ? (rank == 0 && simd < TW) : wv < TW);
-    const int role_idx = seg ? ((simd & 1) * 2 + rank)
-                             : (even ? (is_tree ? simd : (TW == 4 ? simd : (rank == 0 ? 4 : simd))) : (wv < TW ? wv : wv - TW));
+    // (segregated roles -- both waves of SIMDs 0-1 walk trees, both waves of SIMDs 2-3 run the network, so that no tree wave loses
+    // vector-issue slots to a neighbour's MFMAs -- measured -9.5 % with the f32x3 net, -2 % with the fp16 net: two network waves
+    // then share one MFMA pipe.  profiles/r03_ab_pair_split_and_roles.json)
+    const bool is_tree = even ? (rank == 0 && simd < TW) : wv < TW;
+    const int role_idx = even ? (is_tree ? simd : (TW == 4 ? simd : (rank == 0 ? 4 : simd))) : (wv < TW ? wv : wv - TW);
     const unsigned long long t_launch = __builtin_amdgcn_s_memtime();
     const unsigned long long quantum = (unsigned long long)n_steps * (unsigned long long)(d.time_budget > 0 ? d.time_budget : 80000);
     unsigned long long t_busy = 0, n_pass = 0;   // diagnostic (C4_TREE_STAMPS=1)
@@ -1833,98 +1853,124 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
             if (grp < SPW && sl < TS)
                 tree_step<C4_EVAL_EXTERNAL_F32, false, true, true, true, const_dev, true>(d, wg_first + sl * wg_stride, lane, sl, s_path, s_l1, s_val, s_pri, nullptr,
                                                                                           nullptr, &smem[sl], sl, s_stats, t_launch + quantum,
-                                                                                          &s_req[sl]);
+                                                                                          &s_req[sl], TS);
             lds_fence();
             if (d.has_stamps) t_busy += __builtin_amdgcn_s_memtime() - ta;
         }
         if ((threadIdx.x & 63) == 0) atomicAdd(&s_tree_done, 1u);
     } else {
-        const int nw = role_idx;   // network wave index: its planes
         const int lw = threadIdx.x & 63;
-        for (;;) {
-            const uint32_t done = lds_ld(&s_tree_done);   // read BEFORE the requests: no post can follow a full count
-            const uint32_t r = lw < TS ? lds_ld(&s_req[lw]) : REQ_IDLE;
-            unsigned long long m = __builtin_amdgcn_ballot_w64(r == REQ_POSTED);
-            if (m == 0) {
-                if (done == (uint32_t)TW) break;
-                __builtin_amdgcn_s_sleep(4);
-                continue;
-            }
-            // start looking at a different slot on every network wave, so that they do not race for the same request
-            const int rot = (nw * TS) / NW;
-            constexpr unsigned long long ALL = (TS == 64) ? ~0ull : ((1ull << TS) - 1);
-            auto first_from = [&](unsigned long long mm) -> int {
-                const unsigned long long mr = ((mm >> rot) | (mm << (TS - rot))) & ALL;
-                return __builtin_amdgcn_readfirstlane((__builtin_ctzll(mr) + rot) % TS);
-            };
-            auto claim = [&](int slot) -> int {
-                int ok = 0;
-                if (lw == 0) ok = atomicCAS(&s_req[slot], REQ_POSTED, REQ_TAKEN) == REQ_POSTED;
-                return __builtin_amdgcn_readfirstlane(ok);
-            };
-            const int c = first_from(m);
-            if (!claim(c)) continue;
-            const unsigned long long ta = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
-            m &= ~(1ull << c);
-            int c2 = -1;
-            if (PAIRS && m != 0) {   // a second request is waiting: both in one pass (12 independent accumulator tiles keep the MFMA pipe busier)
-                c2 = first_from(m);
-                if (!claim(c2)) c2 = -1;
-            }
-            if (PAIRS && c2 >= 0) {
-                const uint64_t a0[2] = {smem[c].leaf0, smem[c2].leaf0}, a1[2] = {smem[c].leaf1, smem[c2].leaf1};
-                const int o[2] = {c, c2};
-                net_forward_wave16n<2>(nd, &act[nw][0], mlp, s_bias, s_tab16, a0, a1, s_val, s_pri, o);
-            } else {
-                net_forward_wave1_mode<MODE>(nd, &act[nw][0], mlp, s_bias, s_tab16, smem[c].leaf0, smem[c].leaf1, s_val, s_pri, c, s_w0,
-                                             (C4_FUSED_NET_STAMPS && d.has_stamps && blockIdx.x < 16) ? d.cold->stamps + 2048 + (blockIdx.x * NWAVES + nw) * 16 : nullptr);
-            }
-            lds_fence();   // the answer is in LDS before the request word says so
-            if (C4_NET_SANITISES) {   // see tree_step's apply: answers leave this wave finite
-                sanitise_answer(s_val, s_pri, c, lw, s_stats);
-                if (PAIRS && c2 >= 0) sanitise_answer(s_val, s_pri, c2, lw, s_stats);
-                lds_fence();
-            }
-            // (speculation, below) the answered position and its priors, read before the slot may reuse its rows
-            const uint64_t p0 = smem[c].leaf0, p1 = smem[c].leaf1;
-            const float ppr = (SPECULATE && lw < 7) ? s_pri[c * 7 + lw] : -1.0f;
-            if (lw == 0) {
-                lds_st(&s_req[c], REQ_ANSWERED);
-                if (PAIRS && c2 >= 0) lds_st(&s_req[c2], REQ_ANSWERED);
-            }
-            if (PAIRS && c2 >= 0) n_pass += 1;
-            if (d.has_stamps) { t_busy += __builtin_amdgcn_s_memtime() - ta; n_pass += 1; }
+        const int nw = role_idx;   // network wave index: its planes, its scratch row
+        unsigned long long *const nstamps = (C4_FUSED_NET_STAMPS && d.has_stamps && blockIdx.x < 16) ? d.cold->stamps + 2048 + (blockIdx.x * NWAVES + nw) * 16 : nullptr;
+        {
             // ---- speculative evaluation.  The evaluator's answer depends on the position alone and the evaluation cache is
             // transparent (evaluators.py:9-25 memo table), so evaluating a position EARLY changes no result.  The next
             // simulation that reaches the node just answered ends on its child with the highest prior (all children
             // unvisited: the PUCT score is pb_c x prior, mcts.py:147-161), and first-play-urgency 0 keeps the search on
-            // that child for a long time: most evaluator calls of a search are such positions.  With no real request
-            // waiting, this wave evaluates that child now and puts the answer into the cache; when the search gets there
-            // its probe hits instead of costing the slot a network round trip.  Tree waves do nothing for it.
-            if (SPECULATE && !(PAIRS && c2 >= 0) && d.cache != nullptr) {
-                const uint32_t r2 = lw < TS ? lds_ld(&s_req[lw]) : REQ_IDLE;
-                if (__builtin_amdgcn_ballot_w64(r2 == REQ_POSTED) != 0) continue;   // real work first
-                uint64_t c0 = p0, c1 = p1;
-                int go_spec = 0;
-                if (lw < GROUP) {
-                    const int mask = legal_mask(p0 | p1);
-                    const bool legal = lw < 7 && ((mask >> lw) & 1);
-                    const int kb = group_argmax(legal ? (double)ppr : -1.0, legal ? lw : -1);   // ties: the higher column (tree.py:11-15)
-                    const uint32_t cst = make_move(c0, c1, kb);
-                    float cv, cp;
-                    go_spec = (cst < ST_XWIN && !cache_probe(d, c0, c1, lw, cv, cp)) ? 1 : 0;
+            // that child for a long time: most evaluator calls of a search are such positions.  After a real answer, with no
+            // request waiting, the wave notes that child (if the cache does not hold it) and evaluates it the next time
+            // it finds NO real request: the answer goes into the cache, and when the search gets there its probe hits
+            // instead of costing the slot a network round trip.  Tree waves do nothing for it.  (One call site of the forward
+            // serves both kinds of pass: the kernel carries one copy of it, +1.5 %.)
+            bool have_spec = false;
+            uint64_t sc0 = 0, sc1 = 0;
+            for (;;) {
+                const uint32_t done = lds_ld(&s_tree_done);   // read BEFORE the requests: no post can follow a full count
+                const uint32_t r = lw < TS ? lds_ld(&s_req[lw]) : REQ_IDLE;
+                unsigned long long m = __builtin_amdgcn_ballot_w64(r == REQ_POSTED);
+                // start looking at a different slot on every network wave, so that they do not race for the same request
+                const int rot = (nw * TS) / NW;
+                constexpr unsigned long long ALL = (TS == 64) ? ~0ull : ((1ull << TS) - 1);
+                auto first_from = [&](unsigned long long mm) -> int {
+                    const unsigned long long mr = ((mm >> rot) | (mm << (TS - rot))) & ALL;
+                    return __builtin_amdgcn_readfirstlane((__builtin_ctzll(mr) + rot) % TS);
+                };
+                auto claim = [&](int slot) -> int {
+                    int ok = 0;
+                    if (lw == 0) ok = atomicCAS(&s_req[slot], REQ_POSTED, REQ_TAKEN) == REQ_POSTED;
+                    return __builtin_amdgcn_readfirstlane(ok);
+                };
+                int c = -1, c2 = -1, row;
+                uint64_t b0, b1;
+                if (m != 0) {                       // real work first
+                    c = first_from(m);
+                    if (!claim(c)) continue;
+                    m &= ~(1ull << c);
+                    if (PAIRS && m != 0) {   // a second request is waiting: both in one pass (12 independent accumulator tiles keep the MFMA pipe busier)
+                        c2 = first_from(m);
+                        if (!claim(c2)) c2 = -1;
+                    }
+                    b0 = smem[c].leaf0;
+                    b1 = smem[c].leaf1;
+                    row = c;
+                } else if (SPECULATE && have_spec) {
+                    have_spec = false;
+                    b0 = sc0;
+                    b1 = sc1;
+                    row = TS + nw;
+                } else {
+                    if (done == (uint32_t)TW) break;
+                    __builtin_amdgcn_s_sleep(4);
+                    continue;
                 }
-                go_spec = __builtin_amdgcn_readfirstlane(go_spec);
-                if (!go_spec) continue;
-                c0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(c0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
-                c1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(c1 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)c1);
-                net_forward_wave1_mode<MODE>(nd, &act[nw][0], mlp, s_bias, s_tab16, c0, c1, s_val, s_pri, TS + nw, s_w0);
-                lds_fence();
-                if (C4_NET_SANITISES) { sanitise_answer(s_val, s_pri, TS + nw, lw, s_stats); lds_fence(); }
-                if (lw < GROUP) cache_insert(d, c0, c1, lw, s_val[TS + nw], lw < 7 ? s_pri[(TS + nw) * 7 + lw] : 0.0f);
-                if (lw == 0) atomicAdd(&s_stats[offsetof(SlotStats, spec_evals) / sizeof(uint64_t)], 1u);
-                // (walking further down the line of highest priors -- stepping over cached positions, a second pass -- measured
-                // 3.5 % slower than stopping here: real requests wait while the wave probes)
+                const bool is_spec = c < 0;
+                const unsigned long long ta = d.has_stamps ? __builtin_amdgcn_s_memtime() : 0;
+#if C4_SPLIT_PHASES
+                const uint32_t t_claim = (uint32_t)__builtin_amdgcn_s_memtime();
+                if (!is_spec && lw == 0) { atomicAdd(&s_req[3 * TS + 0], (t_claim - lds_ld(&s_req[TS + c])) >> 6); atomicAdd(&s_req[3 * TS + 3], 1u); }   // posted -> claimed
+#endif
+                if (PAIRS && c2 >= 0) {
+                    const uint64_t a0[2] = {b0, smem[c2].leaf0}, a1[2] = {b1, smem[c2].leaf1};
+                    const int o[2] = {c, c2};
+                    net_forward_wave16n<2>(nd, &act[nw][0], mlp, s_bias, s_tab16, a0, a1, s_val, s_pri, o);
+                } else {
+                    net_forward_wave1_mode<MODE>(nd, &act[nw][0], mlp, s_bias, s_tab16, b0, b1, s_val, s_pri, row, s_w0, nstamps);
+                }
+                lds_fence();   // the answer is in LDS before the request word says so
+                if (C4_NET_SANITISES) {   // see tree_step's apply: answers leave this server finite
+                    sanitise_answer(s_val, s_pri, row, lw, s_stats);
+                    if (PAIRS && c2 >= 0) sanitise_answer(s_val, s_pri, c2, lw, s_stats);
+                    lds_fence();
+                }
+                if (is_spec) {
+                    if (lw < GROUP) cache_insert(d, b0, b1, lw, s_val[row], lw < 7 ? s_pri[row * 7 + lw] : 0.0f);
+                    if (lw == 0) atomicAdd(&s_stats[offsetof(SlotStats, spec_evals) / sizeof(uint64_t)], 1u);
+                    // (walking further down the line of highest priors -- stepping over cached positions, a second pass -- measured
+                    // 3.5 % slower than stopping here: real requests wait while the wave probes)
+                    continue;
+                }
+                // the answered position's priors, read before the slot may reuse its rows
+                const float ppr = (SPECULATE && lw < 7) ? s_pri[c * 7 + lw] : -1.0f;
+                if (lw == 0) {
+#if C4_SPLIT_PHASES
+                    const uint32_t t_ans = (uint32_t)__builtin_amdgcn_s_memtime();
+                    lds_st(&s_req[2 * TS + c], t_ans);
+                    atomicAdd(&s_req[3 * TS + 1], (t_ans - t_claim) >> 6);   // claimed -> answered
+#endif
+                    lds_st(&s_req[c], REQ_ANSWERED);
+                    if (PAIRS && c2 >= 0) lds_st(&s_req[c2], REQ_ANSWERED);
+                }
+                if (PAIRS && c2 >= 0) n_pass += 1;
+                if (d.has_stamps) { t_busy += __builtin_amdgcn_s_memtime() - ta; n_pass += 1; }
+                if (SPECULATE && !(PAIRS && c2 >= 0) && d.cache != nullptr) {
+                    const uint32_t r2 = lw < TS ? lds_ld(&s_req[lw]) : REQ_IDLE;
+                    if (__builtin_amdgcn_ballot_w64(r2 == REQ_POSTED) != 0) continue;   // real work first
+                    uint64_t c0 = b0, c1 = b1;
+                    int go_spec = 0;
+                    if (lw < GROUP) {
+                        const int mask = legal_mask(b0 | b1);
+                        const bool legal = lw < 7 && ((mask >> lw) & 1);
+                        const int kb = group_argmax(legal ? (double)ppr : -1.0, legal ? lw : -1);   // ties: the higher column (tree.py:11-15)
+                        const uint32_t cst = make_move(c0, c1, kb);
+                        float cv, cp;
+                        go_spec = (cst < ST_XWIN && !cache_probe(d, c0, c1, lw, cv, cp)) ? 1 : 0;
+                    }
+                    go_spec = __builtin_amdgcn_readfirstlane(go_spec);
+                    if (!go_spec) continue;
+                    sc0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(c0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
+                    sc1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(c1 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)c1);
+                    have_spec = true;
+                }
             }
         }
     }
@@ -1933,6 +1979,9 @@ __global__ __launch_bounds__(c4net::NTHREADS) void c4_selfplay_split_kernel(cons
         if (TW == 4) d.cold->stamps[blockIdx.x * 16 + (is_tree ? 4 : 12) + role_idx] = (unsigned long long)simd | ((unsigned long long)even << 8);
     }
     __syncthreads();
+#if C4_SPLIT_PHASES
+    if (d.has_stamps && blockIdx.x < 128 && threadIdx.x < 4) d.cold->stamps[4096 + blockIdx.x * 4 + threadIdx.x] = s_req[3 * TS + threadIdx.x];
+#endif
     // ---- launch epilogue: LDS -> global
     for (int i = threadIdx.x; i < TS * MAX_DEPTH; i += NTHREADS) {   // paths of the leaves whose answers wait for the next launch
         const int p = i / MAX_DEPTH, k = i - p * MAX_DEPTH;
@@ -2270,7 +2319,6 @@ struct c4_engine {
     int cus;              // compute units of the device
     int pack_dense;       // C4_FUSED_PACK=dense: consecutive slots per workgroup even when that leaves CUs idle (tests of ragged workgroups)
     int fused_wave;       // 1: wave-autonomous fused kernel (c4_selfplay_wave_kernel); 2: tree waves + network waves (c4_selfplay_split_kernel)
-    int split_seg;        // tuning aid (C4_SPLIT_SEG=1): segregated roles, see c4_selfplay_split_kernel
     int split_tw;         // tuning aid (C4_SPLIT_TW=2|4): tree waves of the split kernel at 16 slots per workgroup; 0 = by net mode
     int tape_games;
     double *tape_noise, *tape_u;
@@ -2364,6 +2412,15 @@ int c4_debug_fused_net_stamps(c4_engine *e, unsigned long long *out)
     return hipMemcpy(out, e->cold.stamps + 2048, 16 * 8 * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? C4_OK : C4_EDEVICE;
 }
 
+/* diagnostic (build with -DC4_SPLIT_PHASES=1): request latency sums of workgroups 0..127 of the last split-kernel launch, [128][4] =
+ * {posted->claimed, claimed->answered, answered->picked up} in units of 64 cycles, and the number of requests */
+int c4_debug_latency_stamps(c4_engine *e, unsigned long long *out)
+{
+    if (!e || !out || !e->cold.stamps) return C4_ESTATE;
+    if (hipDeviceSynchronize() != hipSuccess) return C4_EDEVICE;
+    return hipMemcpy(out, e->cold.stamps + 4096, 128 * 4 * 8, hipMemcpyDeviceToHost) == hipSuccess ? C4_OK : C4_EDEVICE;
+}
+
 int c4_debug_stamps(c4_engine *e, unsigned long long *out)
 {
     if (!e || !out || !e->cold.stamps) return C4_ESTATE;
@@ -2404,8 +2461,6 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
         if (const char *fm = getenv("C4_FUSED_MODE")) e->fused_wave = strcmp(fm, "block") == 0 ? 0 : (strcmp(fm, "wave") == 0 ? 1 : 2);
         e->split_tw = 0;     // 0: chosen by the net's mode
         if (const char *tw = getenv("C4_SPLIT_TW")) e->split_tw = atoi(tw);
-        e->split_seg = 0;
-        if (const char *sg = getenv("C4_SPLIT_SEG")) e->split_seg = atoi(sg);
         if (const char *fs = getenv("C4_FUSED_SLOTS")) {   // tuning aid: force 16 or 32
             const int v = atoi(fs);
             if (v == 16 || v == 32) e->fused_slots = v;
@@ -2505,7 +2560,7 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
     }
     if (getenv("C4_TREE_STAMPS")) {
         unsigned long long *q = nullptr;
-        if (dev_alloc(e, &q, 2 * 256 * 8) == C4_OK) { (void)hipMemset(q, 0, 2 * 256 * 8 * 8); e->cold.stamps = q; }
+        if (dev_alloc(e, &q, 3 * 256 * 8) == C4_OK) { (void)hipMemset(q, 0, 3 * 256 * 8 * 8); e->cold.stamps = q; }
     }
     d.has_stamps = e->cold.stamps != nullptr;
     ALLOC(e->cold_dev, 1);
@@ -2651,8 +2706,7 @@ int c4_selfplay_steps(c4_engine *e, c4_net *net, float *values_dev, float *prior
         const int dense_wgs = (e->d.G + e->fused_slots - 1) / e->fused_slots;
         const int spread = (!e->pack_dense && dense_wgs < e->cus && e->d.G > dense_wgs) ? 1 : 0;
         const dim3 gsp(spread ? std::min(e->cus, e->d.G) : dense_wgs);
-        const int kflags = spread | (e->split_seg ? 2 : 0);
-#define C4_LAUNCH_SPLIT(TSV, MODE, TWV) hipLaunchKernelGGL((c4_selfplay_split_kernel<TSV, MODE, TWV>), gsp, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps, kflags)
+#define C4_LAUNCH_SPLIT(TSV, MODE, TWV) hipLaunchKernelGGL((c4_selfplay_split_kernel<TSV, MODE, TWV>), gsp, blk, 0, st, e->d_dev, nd, values_dev, priors_dev, (int)n_steps, spread)
 #define C4_LAUNCH_WAVE(MODE)                                                                                                       \
     do {                                                                                                                           \
         if (e->fused_wave == 2) {                                                                                                  \

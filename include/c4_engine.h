@@ -358,6 +358,12 @@ int c4_debug_stamps(c4_engine *e, unsigned long long *out);
  * c4_selfplay_steps launch, [16][8][16] (phase order as c4_net_debug_stamps); needs C4_TREE_STAMPS=1, else C4_ESTATE. */
 int c4_debug_fused_net_stamps(c4_engine *e, unsigned long long *out);
 
+/* diagnostic build aid (library built with -DC4_SPLIT_PHASES=1; zeros otherwise): the life of the evaluator requests of the last
+ * c4_selfplay_steps launch, workgroups 0..127, [128][4] = {posted -> claimed by a network wave, claimed -> answered,
+ * answered -> picked up by its tree wave} summed in units of 64 shader cycles, and the number of requests; needs
+ * C4_TREE_STAMPS=1, else C4_ESTATE. */
+int c4_debug_latency_stamps(c4_engine *e, unsigned long long *out);
+
 int c4_abi_version(void);
 
 #ifdef __cplusplus

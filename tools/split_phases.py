@@ -37,3 +37,12 @@ print("share of the launch a slot spends waiting for the network: %.3f   (walkin
       ((wait / (it + wait)).mean(), (it / (it + wait)).mean()))
 print("hit rate %.3f, mean leaf depth %.2f" % ((s1["eval_cache_hits"] - s0["eval_cache_hits"]) / max(1, s1["eval_cache_probes"] - s0["eval_cache_probes"]),
       (s1["depth_sum"] - s0["depth_sum"]) / max(1, s1["simulations"] - s0["simulations"])))
+
+lat = (C.c_uint64 * 512)()
+if sp.engine._lib.c4_debug_latency_stamps(sp.engine._h, lat) == 0:
+    q = np.array(list(lat), dtype=np.float64).reshape(128, 4)
+    q = q[q[:, 3] > 0]
+    if len(q):
+        n = q[:, 3].sum()
+        print("a request's life (mean over %d requests of the last launch, cycles): posted -> claimed %.0f, claimed -> answered %.0f, answered -> picked up %.0f"
+              % (n, 64 * q[:, 0].sum() / n, 64 * q[:, 1].sum() / n, 64 * q[:, 2].sum() / n))

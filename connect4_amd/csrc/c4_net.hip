@@ -25,7 +25,7 @@
 // Several forwards share this arithmetic: net_forward_block (above; c4_net_forward for the 32-filter fp16 net, the
 // workgroup-synchronous self-play kernel) and the wave-private forwards on 16-row MFMA tiles -- one wave = one position,
 // private LDS planes, weights streamed from L2 into registers, no workgroup barrier: net_forward_wave16 (32 filters, fp16;
-// bit-identical to the block forward; c4_net_forward_wave and the self-play kernels), net_forward_wave16p (32 filters,
+// bit-identical to the block forward; c4_net_forward_wave and the self-play kernels), net_forward_wave16q (32 filters,
 // reference precision), net_forward_wave16w (64 filters).  All live in c4_net_dev.h.
 #include <hip/hip_runtime.h>
 
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NTHREADS) void c4_net_kernel(NetDev nd, const uint6
     net_forward_block(nd, NetLds{lds, wbuf, mlp}, c0, c1, n, blockIdx.x * P, values, priors);
 }
 
-// One-position wave-private forward (net_forward_wave16p: reference precision at 32 filters; net_forward_wave16w: fp16 at
+// One-position wave-private forward (net_forward_wave16q: reference precision at 32 filters; net_forward_wave16w: fp16 at
 // 64 filters): one position per wave.  Both c4_net_forward and c4_net_forward_wave run this kernel for such a net (one
 // implementation, so the two entry points and the fused self-play kernel cannot disagree).
 template <int MODE>

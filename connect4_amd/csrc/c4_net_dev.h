@@ -46,7 +46,7 @@ struct NetDev {
     int mode;              // NETMODE_* the kernels are specialised for
     // 32 filters: the same weights in the fragment order of v_mfma_f32_16x16x32_f16 (net_forward_wave16) ...
     const half8 *stem_w16, *conv_w16, *head_w16;
-    // ... and, for the reference-precision mode, their scaled low parts (net_forward_wave16p)
+    // ... and, for the reference-precision mode, their scaled low parts (net_forward_wave16q)
     const half8 *stem_w16l, *conv_w16l, *head_w16l;
     // ... and the tower as ONE linear stream for net_forward_wave16q: per tower tap T four fragments
     // [cout tile 0 hi][cout tile 0 lo][cout tile 1 hi][cout tile 1 lo] x 64 lanes x 16 bytes = 4,096 bytes
@@ -437,12 +437,12 @@ __device__ __forceinline__ void net_forward_block(const NetDev &nd, const NetLds
 // so all forwards of one net give bit-identical answers (tests/test_gpu_fused_net.py).
 // All of them run on 16-row MFMA tiles (v_mfma_f32_16x16x32_f16: the position's 42 pixels are 3 row tiles):
 //   net_forward_wave16n<NP>     32 filters, fp16 storage: the self-play kernels' hot forward, NP positions per pass
-//   net_forward_wave16p         32 filters, reference precision (fp16 hi + lo split)
+//   net_forward_wave16q         32 filters, reference precision (fp16 hi + lo split)
 //   net_forward_wave16w         64 filters, fp16 storage
 // (Earlier rounds had forwards on 32-row tiles -- two positions per pass, then one position in two half-empty tiles:
 // 22-27 k cycles per pass at 32 filters where the 16-row forward takes 17-20 k; retired.)
 // ------------------------------------------------------------------------------------------------
-// Reference precision (C4_NET_F32X3, net_forward_wave16p): every fp32 operand x (folded weight, activation) is
+// Reference precision (C4_NET_F32X3, net_forward_wave16q): every fp32 operand x (folded weight, activation) is
 // carried as two fp16 numbers
 //     x  ~=  hi + lo / 2^11,      hi = f16(x),   lo = f16((x - hi) * 2^11)
 // (x - hi is exact in fp32; scaling keeps lo a NORMAL fp16 of x's own magnitude), and a product of two
@@ -777,12 +777,13 @@ __device__ __forceinline__ void net_forward_wave16(const NetDev &nd, _Float16 *b
 }
 
 // ------------------------------------------------------------------------------------------------
-// net_forward_wave16p: the reference-precision forward (C4_NET_F32X3, see net_forward_wave1 for the
-// arithmetic: x ~= hi + lo / 2^11 in fp16, hi*hi into one accumulator, hi*lo + lo*hi into a second one) on
-// the 16-row tiles of net_forward_wave16: 9 taps x 3 row tiles x 2 cout tiles x 3 = 162 MFMAs of 16 cycles per
-// layer instead of 108 of 32, four planes (ping/pong x hi/lo) of 43 rows x 96 bytes, the hi and lo weight
-// fragments of a tap stream from L2 through a rolling window of three taps (the tower's taps are one linear
-// sequence in memory).
+// The reference-precision forward (C4_NET_F32X3; net_forward_wave16q below; arithmetic: x ~= hi + lo / 2^11 in fp16, hi*hi
+// into one accumulator, hi*lo + lo*hi into a second one) on the 16-row tiles of net_forward_wave16: 9 taps x 3 row tiles
+// x 2 cout tiles x 3 = 162 MFMAs of 16 cycles per layer, four planes (ping/pong x hi/lo) of 43 rows x 96 bytes, the hi
+// and lo weight fragments of a tap stream from L2 through a rolling window of three taps (the tower's taps are one
+// linear sequence in memory).  (Round 2's version of it, net_forward_wave16p -- same arithmetic, 64-bit vector addresses
+// per weight load, compiler-chosen instruction order: 4.0-4.6 k cycles per layer's k-loop -- was retired in round 3 after
+// the bit-for-bit comparison on the device, profiles/r03_ab_f32x3_lean_forward.json.)
 // ------------------------------------------------------------------------------------------------
 constexpr int WTAPS = 3;   // taps of weights in flight (divides 9: a tap's window slot is t % 3 in every layer)
 
@@ -802,245 +803,11 @@ __device__ __forceinline__ void store16p(const floatx4 &hi, const floatx4 &lo, _
     }
 }
 
-__device__ __forceinline__ void net_forward_wave16p(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds,
-                                                    const uint16_t *tab, uint64_t b0, uint64_t b1, float *__restrict__ values,
-                                                    float *__restrict__ priors, int out, unsigned long long *stamps = nullptr)
-{
-    int lane_ = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane_));     // keep lane-derived addresses out of a persistent caller's loop (see net_forward_wave16)
-    const int lane = lane_;
-    const int n = lane & 15, g = lane >> 4;
-    auto stamp = [&](int i) { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); };
-    stamp(0);
-    const int n_layers = 2 * nd.n_res;
-    _Float16 *const p0h = buf, *const p0l = buf + PLANE16, *const p1h = buf + 2 * PLANE16, *const p1l = buf + 3 * PLANE16;
-    // rolling weight window: fragment (tap T of the tower, cout tile ct) at [(T * 2 + ct) * 64 + lane], hi and lo
-    half8 wh[WTAPS][2], wl[WTAPS][2];
-    const half8 *wph = nd.conv_w16 + lane, *wpl = nd.conv_w16l + lane;
-    const int total_taps = n_layers * 9;
-#pragma unroll
-    for (int t = 0; t < WTAPS; ++t) {
-        const int T = t < total_taps ? t : 0;
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) { wh[t][ct] = wph[(T * 2 + ct) * 64]; wl[t][ct] = wpl[(T * 2 + ct) * 64]; }
-    }
-    half8 swh[4], swl[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { swh[i] = nd.stem_w16[i * 64 + lane]; swl[i] = nd.stem_w16l[i * 64 + lane]; }
-    const half8 hwh = nd.head_w16[lane], hwl = nd.head_w16l[lane];   // the heads' fragments and biases: requested a whole tower ahead
-    const float hb0 = nd.head_b[0], hb1 = nd.head_b[1], hb2 = nd.head_b[2];
-    uint32_t tb[TAB16 / 2];
-    {
-        const uint4 *t4 = reinterpret_cast<const uint4 *>(tab + lane * TAB16);
-#pragma unroll
-        for (int i = 0; i < TAB16 / 8; ++i) { const uint4 v = t4[i]; tb[4 * i] = v.x; tb[4 * i + 1] = v.y; tb[4 * i + 2] = v.z; tb[4 * i + 3] = v.w; }
-    }
-    auto tof = [&](int idx) -> int { return (int)((tb[idx >> 1] >> (16 * (idx & 1))) & 0xffffu); };
-    // input planes (board.py:147-154), 4 halves per row, at the start of p1h (the tower writes it only after the stem)
-    _Float16 *inp = p1h;
-    if (lane <= PIX) {
-        half4 v = {};
-        if (lane < PIX) {
-            const int y = lane / 7, x = lane - y * 7;
-            const int bit = x * 7 + (5 - y);
-            v[0] = (_Float16)((__popcll(b0 | b1) & 1) ? 0.0f : 1.0f);
-            v[1] = (_Float16)(float)((b0 >> bit) & 1);
-            v[2] = (_Float16)(float)((b1 >> bit) & 1);
-        }
-        *reinterpret_cast<half4 *>(inp + lane * 4) = v;   // lane == PIX: the zero row of the planes
-    }
-    if (lane < CS16) {
-        p0h[PIX * CS16 + lane] = (_Float16)0.0f; p0l[PIX * CS16 + lane] = (_Float16)0.0f;
-        p1h[PIX * CS16 + lane] = (_Float16)0.0f; p1l[PIX * CS16 + lane] = (_Float16)0.0f;
-    }
-    bool real[RT16];
-    int rbase[RT16];
-#pragma unroll
-    for (int rt = 0; rt < RT16; ++rt) {
-        real[rt] = 16 * rt + n < PIX;
-        rbase[rt] = (real[rt] ? 16 * rt + n : PIX) * CS16;
-    }
-    auto bias4 = [&](const float *b, int ct) -> floatx4 {
-        const float4 v = *reinterpret_cast<const float4 *>(b + 16 * ct + 4 * g);
-        return floatx4{v.x, v.y, v.z, v.w};
-    };
-    const floatx4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    // ------------------------------------------------------------------ stem (0/1 inputs: two MFMAs per step)
-    {
-        floatx4 ah[RT16][2], al[RT16][2];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const floatx4 bv = bias4(bias_lds, ct);
-#pragma unroll
-            for (int rt = 0; rt < RT16; ++rt) { ah[rt][ct] = bv; al[rt][ct] = zero4; }
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int rt = 0; rt < RT16; ++rt) {
-                const half4 va = *reinterpret_cast<const half4 *>(inp + tof(27 + rt * 4 + s * 2));
-                const half4 vb = *reinterpret_cast<const half4 *>(inp + tof(27 + rt * 4 + s * 2 + 1));
-                half8 bf;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { bf[j] = va[j]; bf[4 + j] = vb[j]; }
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    ah[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(swh[s * 2 + ct], bf, ah[rt][ct], 0, 0, 0);
-                    al[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(swl[s * 2 + ct], bf, al[rt][ct], 0, 0, 0);
-                }
-            }
-#pragma unroll
-        for (int rt = 0; rt < RT16; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) store16p(ah[rt][ct], al[rt][ct], p0h, p0l, rbase[rt] + 16 * ct + 4 * g, real[rt]);
-    }
-    stamp(1);
-    // ------------------------------------------------------------------ residual tower
-    // one conv layer; `second` is a compile-time constant, so the plane offsets of all operand reads and stores are immediates
-    auto layer = [&](auto second_tag, const int L) {
-        constexpr bool second = decltype(second_tag)::value;
-        const _Float16 *sh = second ? p1h : p0h, *sl = second ? p1l : p0l;
-        _Float16 *dh = second ? p0h : p1h, *dl = second ? p0l : p1l;
-        floatx4 ah[RT16][2], al[RT16][2];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const floatx4 bv = bias4(bias_lds + F * (1 + L), ct);
-#pragma unroll
-            for (int rt = 0; rt < RT16; ++rt) { ah[rt][ct] = bv; al[rt][ct] = zero4; }
-        }
-        half8 bh[RT16], bl[RT16], nh[RT16], nl[RT16];
-#pragma unroll
-        for (int rt = 0; rt < RT16; ++rt) {
-            bh[rt] = *reinterpret_cast<const half8 *>(sh + tof(rt * 9));
-            bl[rt] = *reinterpret_cast<const half8 *>(sl + tof(rt * 9));
-        }
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            if (t + 1 < 9) {
-#pragma unroll
-                for (int rt = 0; rt < RT16; ++rt) {
-                    nh[rt] = *reinterpret_cast<const half8 *>(sh + tof(rt * 9 + t + 1));
-                    nl[rt] = *reinterpret_cast<const half8 *>(sl + tof(rt * 9 + t + 1));
-                }
-            }
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const half8 cwh = wh[t % WTAPS][ct], cwl = wl[t % WTAPS][ct];
-#pragma unroll
-                for (int rt = 0; rt < RT16; ++rt) {
-                    ah[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cwh, bh[rt], ah[rt][ct], 0, 0, 0);
-                    al[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cwl, bh[rt], al[rt][ct], 0, 0, 0);
-                    al[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cwh, bl[rt], al[rt][ct], 0, 0, 0);
-                }
-            }
-            {   // refill the window slot just used with tap (L*9 + t + WTAPS) of the tower; unconditional (past the end
-                // it re-reads tap 0: a branch around the loads would drain vmcnt)
-                int T = L * 9 + t + WTAPS;
-                T = T < total_taps ? T : 0;
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) { wh[t % WTAPS][ct] = wph[(T * 2 + ct) * 64]; wl[t % WTAPS][ct] = wpl[(T * 2 + ct) * 64]; }
-            }
-#pragma unroll
-            for (int rt = 0; rt < RT16; ++rt) { bh[rt] = nh[rt]; bl[rt] = nl[rt]; }
-        }
-        if (L == C4_NET_STAMP_LAYER) stamp(12);
-        if (second) {   // + block input (lives in dh/dl): identity MFMAs keep it exact in both accumulators
-#pragma unroll
-            for (int rt = 0; rt < RT16; ++rt) {
-                const half8 xh = *reinterpret_cast<const half8 *>(dh + rbase[rt] + 8 * g);
-                const half8 xl = *reinterpret_cast<const half8 *>(dl + rbase[rt] + 8 * g);
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    half8 idf;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) idf[j] = (_Float16)((8 * g + j) == 16 * ct + n ? 1.0f : 0.0f);
-                    ah[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(idf, xh, ah[rt][ct], 0, 0, 0);
-                    al[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(idf, xl, al[rt][ct], 0, 0, 0);
-                }
-            }
-        }
-        if (L == C4_NET_STAMP_LAYER) stamp(13);
-#pragma unroll
-        for (int rt = 0; rt < RT16; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) store16p(ah[rt][ct], al[rt][ct], dh, dl, rbase[rt] + 16 * ct + 4 * g, real[rt]);
-        if (L == C4_NET_STAMP_LAYER) stamp(14);
-        if (L < 6) stamp(2 + L);
-    };
-    for (int blk = 0; blk < nd.n_res; ++blk) {
-        layer(std::false_type{}, 2 * blk);
-        layer(std::true_type{}, 2 * blk + 1);
-    }
-    stamp(8);
-    // ------------------------------------------------------------------ 1x1 head convs
-    float *hs = reinterpret_cast<float *>(p1h);   // [HSTR] fp32 (p1 is free)
-    {
-        floatx4 a[RT16], b[RT16];
-#pragma unroll
-        for (int rt = 0; rt < RT16; ++rt) {
-            const half8 xh = *reinterpret_cast<const half8 *>(p0h + rbase[rt] + 8 * g);
-            const half8 xl = *reinterpret_cast<const half8 *>(p0l + rbase[rt] + 8 * g);
-            a[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwh, xh, zero4, 0, 0, 0);
-            b[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwl, xh, zero4, 0, 0, 0);
-            b[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwh, xl, b[rt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int rt = 0; rt < RT16; ++rt) {
-            const int r = 16 * rt + n;
-            if (g == 0 && r < PIX) {
-                hs[0 * PIX + r] = lrelu(a[rt][0] + b[rt][0] * LO_INV + hb0);
-                hs[1 * PIX + r] = lrelu(a[rt][1] + b[rt][1] * LO_INV + hb1);
-                hs[2 * PIX + r] = lrelu(a[rt][2] + b[rt][2] * LO_INV + hb2);
-            }
-        }
-        if (lane < 2) hs[HEADV + lane] = 0.0f;   // pad 126,127
-    }
-    stamp(9);
-    // ------------------------------------------------------------------ MLP heads (fp32 VALU), as in net_forward_block
-    {
-        const float *vt_b = reinterpret_cast<const float *>(mlp + VT_F4 + PT_F / 4);   // fc_b | vout_w | pfc_b
-        const float *pt = reinterpret_cast<const float *>(mlp + VT_F4);
-        const float4 *hA4 = reinterpret_cast<const float4 *>(hs);
-        float v0 = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 11; ++q) {
-            const float4 wv = mlp[q * 64 + lane];
-            const float4 xa = hA4[q];
-            v0 += wv.x * xa.x + wv.y * xa.y + wv.z * xa.z + wv.w * xa.w;
-        }
-        const int seg = lane >> 3;
-        const float *hpA = hs + PIX + seg * 11;
-        float l0 = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 11; ++c) {
-            const float wv = pt[c * 64 + lane];      // zero where seg*11 + c >= 84 or (lane & 7) == 7
-            const int cc = seg * 11 + c < 2 * PIX ? c : 2 * PIX - 1 - seg * 11;
-            l0 += wv * hpA[cc];
-        }
-        l0 += dppf<0x128>(l0);
-#pragma unroll
-        for (int m = 16; m <= 32; m <<= 1) l0 += __shfl_xor(l0, m, 64);
-        const float fb = vt_b[lane], vw = vt_b[64 + lane], pb = vt_b[128 + lane];
-        const bool is_pol = lane < 7;
-        const float a = v0 + fb;
-        const float lg = l0 + pb;
-        const float rs = sum16(lane < PIX ? vw * lrelu(a) : 0.0f);               // model.py:83-85
-        const float vsum = readlane_f(rs, 0) + readlane_f(rs, 16) + readlane_f(rs, 32);
-        const float value = (tanhf(vsum + nd.vout_b) + nd.w1) * nd.w2;           // model.py:86-88
-        const float mx = max8(is_pol ? lg : -INFINITY);
-        const float e = is_pol ? expf(lg - mx) : 0.0f;
-        const float sum = sum8(e);
-        if (lane == 0) values[out] = value;
-        if (is_pol) priors[(size_t)out * 7 + lane] = e / sum;
-    }
-    stamp(10);
-}
-
 // ------------------------------------------------------------------------------------------------
-// net_forward_wave16q: net_forward_wave16p's arithmetic, operation for operation (same products, same accumulation
-// order per accumulator, same roundings: bit-identical answers), with a leaner instruction stream -- one wave on a SIMD
-// cannot issue its MFMAs back to back when ~30 other instructions per tap stand between them (round 3: 4.0-4.6 k
-// cycles per layer's k-loop against 2.6 k of MFMA time, alone on a CU as well as inside the self-play kernel):
+// net_forward_wave16q: the one-position reference-precision forward, with an instruction stream lean enough for ONE wave to
+// keep its SIMD's MFMA pipe fed -- a wave cannot issue its MFMAs back to back when ~30 other instructions per tap stand
+// between them in clusters (round 2: 4.0-4.6 k cycles per layer's k-loop against 2.6 k of MFMA time, alone on a CU as
+// well as inside the self-play kernel; now 3.0-3.2 k):
 //   * the tower's weights are ONE linear stream read with buffer loads: scalar tap offset + a lane offset fixed for the
 //     whole pass + an immediate per fragment -- no 64-bit vector address arithmetic per load (and no MFMA-operand /
 //     address register hazards with their s_nops), no clamp at the end of the tower (a buffer load past the end of the
@@ -1048,13 +815,11 @@ __device__ __forceinline__ void net_forward_wave16p(const NetDev &nd, _Float16 *
 //   * what a pass needs FIRST -- the stem's and the heads' fragments, the tower's first two taps -- lives in LDS for the whole
 //     launch (18 KB per workgroup, stage_w0_lds): a pass no longer starts with an L2 round trip in front of its first MFMA;
 //   * group barriers spread the next tap's operand reads and the weight requests between the MFMAs instead of in
-//     clusters in front of them (C4_F32X3_SGB);
+//     clusters in front of them (C4_F32X3_SGB; with buffer loads but WITHOUT them the compiler's order is 30 % slower
+//     than round 2's);
 //   * the epilogue runs on packed float32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two values per
 //     instruction; hi + lo * 2^-11 as ONE fma -- the product is exact, so the rounding is the add's).
 // ------------------------------------------------------------------------------------------------
-#ifndef C4_F32X3_LEAN
-#define C4_F32X3_LEAN 1
-#endif
 #ifndef C4_F32X3_SGB
 #define C4_F32X3_SGB 1
 #endif
@@ -1603,7 +1368,7 @@ constexpr int NETMODE_F32_F16 = 0;    // 32 filters, fp16 storage: net_forward_w
 constexpr int NETMODE_F32_PRECISE = 1;
 constexpr int NETMODE_F64 = 2;        // 64 filters, fp16 storage, one position per pass
 // LDS for the fragments a pass needs first (only the reference-precision forward keeps any)
-template <int MODE> struct W0Lds { static constexpr int FRAGS = (MODE == NETMODE_F32_PRECISE && C4_F32X3_LEAN) ? W0_FRAGS * 64 : 1; };
+template <int MODE> struct W0Lds { static constexpr int FRAGS = MODE == NETMODE_F32_PRECISE ? W0_FRAGS * 64 : 1; };
 template <int MODE>
 __device__ __forceinline__ void net_forward_wave1_mode(const NetDev &nd, _Float16 *buf, const float4 *mlp, const float *bias_lds,
                                                        const uint16_t *tab, uint64_t b0, uint64_t b1, float *__restrict__ values,
@@ -1611,13 +1376,8 @@ __device__ __forceinline__ void net_forward_wave1_mode(const NetDev &nd, _Float1
                                                        unsigned long long *stamps = nullptr)
 {
     if constexpr (MODE == NETMODE_F64) net_forward_wave16w(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, stamps);
-    else if constexpr (MODE == NETMODE_F32_PRECISE) {
-#if C4_F32X3_LEAN
-        net_forward_wave16q(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, w0, stamps);
-#else
-        net_forward_wave16p(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, stamps);
-#endif
-    } else net_forward_wave16(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, stamps);
+    else if constexpr (MODE == NETMODE_F32_PRECISE) net_forward_wave16q(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, w0, stamps);
+    else net_forward_wave16(nd, buf, mlp, bias_lds, tab, b0, b1, values, priors, out, stamps);
 }
 // halves of private LDS a wave needs for its planes in each mode
 template <int MODE> struct WaveBuf {

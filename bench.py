@@ -4,7 +4,10 @@
 Workload (BASELINE.json configs[1]): 4096 parallel self-play games per GPU, 800 simulations per
 move, random-init residual policy/value net (32 filters, 3 residual blocks), self-play settings
 (Dirichlet alpha 0.3, fraction 0.25, 6 sampled opening moves).  Synthetic data: games start from the
-empty board, weights are seeded random-init.
+empty board, weights are seeded random-init.  Leaves are evaluated in the REFERENCE's precision (the reference's net is
+float32, model.py:252-282): `dtype: "f32x3"` = every fp32 operand as an fp16 hi + lo pair, three MFMAs per product, fp32
+accumulation.  The opt-in fp16-storage mode (`--net-precision f16`) is timed in a short second run and reported as the
+secondary block `f16_storage_mode` of the same line -- it is NOT the headline.
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -19,7 +22,8 @@ is meaningless on 4096 identical empty boards with a cold evaluation cache): lau
 a game and the evaluation cache (the reference's memo table, evaluators.py:9-25) holds the openings.
 It is reported as preroll_s / preroll_steps / preroll_games.
 
-N>1: `python bench.py --gpus N` starts N rank processes itself (torch.distributed.run, one per GPU,
+N>1 (scaling runs use the default `--slots 4096` games PER GPU, so N = 1 is exactly this line; BASELINE configs[2]'s 65,536 games
+on 8 GPUs are `--slots 8192`): `python bench.py --gpus N` starts N rank processes itself (torch.distributed.run, one per GPU,
 before anything touches the GPU) and relays rank 0's JSON line; under an external torchrun it uses
 the RANK/LOCAL_RANK/WORLD_SIZE it finds.  Games shard across ranks (disjoint RNG streams seed+rank),
 there is NO collective inside the rollout path (weak scaling).  Rank 0 prints ONE JSON line.
@@ -62,7 +66,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed steps (one persistent-kernel launch each)")
     ap.add_argument("--warmup", type=int, default=5, help="untimed steps after the pre-roll")
-    ap.add_argument("--slots", type=int, default=4096, help="parallel games per GPU")
+    ap.add_argument("--slots", type=int, default=4096,
+                    help="parallel games PER GPU (weak scaling: --gpus N plays N x this many; the default is BASELINE configs[1] and what a "
+                         "scaling run should keep so that N = 1 equals the single-GPU line; configs[2] = --gpus 8 --slots 8192)")
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--filters", type=int, default=32, help="net width (32 = the reference's default / BASELINE config; 64 = its example_config)")
     ap.add_argument("--residuals", type=int, default=3)

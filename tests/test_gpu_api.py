@@ -203,18 +203,20 @@ def test_fused_selfplay_kernel_equals_separate_kernels(monkeypatch):
     assert out[0][1]["bad_evals"] == 0
 
 
+@pytest.mark.parametrize("precision", ["f32x3", "f16"])
 @pytest.mark.parametrize("cache_bits", [-1, 8, 0])
-def test_split_kernel_edge_cases_play_the_same_games(monkeypatch, cache_bits):
+def test_split_kernel_edge_cases_play_the_same_games(monkeypatch, cache_bits, precision):
     """Tree waves + network waves against the wave-autonomous kernel where their hand-off is stressed: no evaluation
     cache at all (every leaf goes to a network wave; no speculation), a 256-entry cache (constant eviction, speculative
     inserts overwrite real ones and vice versa), the default cache; 19 slots (one full and one ragged workgroup, tree
     waves with 0..1 slots), more slots than games (slots park while others still play), launches of a single quantum
-    (every launch ends with leaves in flight that the next one must pick up).  Same seed => same games, id by id."""
+    (every launch ends with leaves in flight that the next one must pick up).  Same seed => same games, id by id.  Both nets:
+    the fp16 net's network waves speculate, the reference-precision net's do not."""
     from connect4_amd.config import MCTSConfig
     from connect4_amd.fused_net import FusedNet
     from connect4_amd.net import random_init_state_dict
     from connect4_amd.selfplay import SelfPlay
-    net = FusedNet(random_init_state_dict(seed=0))
+    net = FusedNet(random_init_state_dict(seed=0), precision=precision)
     cfg = MCTSConfig.self_play(32)
     out = []
     monkeypatch.setenv("C4_FUSED_PACK", "dense")    # one full and one ragged workgroup
@@ -230,8 +232,10 @@ def test_split_kernel_edge_cases_play_the_same_games(monkeypatch, cache_bits):
         st = sp.stats()
         sp.close()
         assert len(games) == 12 and st["bad_evals"] == 0
-        if mode == "split" and cache_bits >= 0:
+        if mode == "split" and cache_bits >= 0 and precision == "f16":
             assert st["speculative_evals"] > 0
+        if precision == "f32x3":
+            assert st["speculative_evals"] == 0
         if cache_bits < 0:
             assert st["speculative_evals"] == 0 and st["eval_cache_hits"] == 0
         out.append(([(g.game_id, g.moves, g.result.value, g.values, [list(p) for p in g.priors]) for g in games],
@@ -242,7 +246,7 @@ def test_split_kernel_edge_cases_play_the_same_games(monkeypatch, cache_bits):
 
 @pytest.mark.parametrize("kind", ["f32x3", "64f"])
 def test_split_kernel_other_nets_play_the_same_games(monkeypatch, kind):
-    """The reference-precision net (net_forward_wave16p in the network waves) and the 64-filter net (net_forward_wave16w;
+    """The reference-precision net (net_forward_wave16q in the network waves) and the 64-filter net (net_forward_wave16w;
     two tree waves of eight slots and six network waves, c4_selfplay_split_kernel<16, MODE, 2>): same seed => the games
     of the wave-autonomous kernel and of the separate kernels (c4_step + c4_net_forward), id by id."""
     from connect4_amd.config import MCTSConfig

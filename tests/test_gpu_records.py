@@ -9,12 +9,12 @@ from conftest import load_json, load_npz
 pytestmark = pytest.mark.gpu
 
 
-def _selfplay(n_slots, sims, games_target, rec_cap, seed=3, **kw):
+def _selfplay(n_slots, sims, games_target, rec_cap, seed=3, precision=None, **kw):
     from connect4_amd.config import MCTSConfig
     from connect4_amd.fused_net import FusedNet
     from connect4_amd.net import random_init_state_dict
     from connect4_amd.selfplay import SelfPlay
-    net = FusedNet(random_init_state_dict(seed=0))
+    net = FusedNet(random_init_state_dict(seed=0), precision=precision)
     sp = SelfPlay(net, n_slots, MCTSConfig.self_play(sims), seed=seed, games_target=games_target,
                   record_capacity_games=rec_cap, use_graph=False, fused_loop=True, steps_per_launch=16, **kw)
     return sp, net
@@ -149,11 +149,12 @@ def test_eval_cache_lookup_returns_the_nets_answers():
 
 
 def test_speculative_evaluations_are_the_nets_answers(oracle):
-    """The split kernel's network waves evaluate positions ahead of the search (the best-prior child of a position they
-    just answered) and insert them into the evaluation cache.  That is invisible to the search only if such an entry
-    holds exactly what the evaluator answers for that position: every cached child of every recorded root -- entries
-    written by real requests and by speculative passes alike -- must equal the wave-private forward bit for bit."""
-    sp, net = _selfplay(32, 24, 64, 64, seed=9, eval_cache_log2_entries=22)
+    """With the fp16 net the split kernel's network waves evaluate positions ahead of the search (the best-prior child of a
+    position they just answered) and insert them into the evaluation cache.  That is invisible to the search only if such an
+    entry holds exactly what the evaluator answers for that position: every cached child of every recorded root -- entries
+    written by real requests and by speculative passes alike -- must equal the wave-private forward bit for bit.  (With the
+    reference-precision net the network waves do not speculate: a pass is too long to put in front of a real request.)"""
+    sp, net = _selfplay(32, 24, 64, 64, seed=9, precision="f16", eval_cache_log2_entries=22)
     for _ in range(400):
         sp.run_steps(64)
         if sp.stats()["active_slots"] == 0:

@@ -233,6 +233,69 @@ def test_sharded_generation_two_ranks_one_card():
     assert outs[0][3] == want_moves
 
 
+def _generation_worker(rank, world, port, save_dir, q):
+    import hashlib
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from connect4_amd.config import MCTSConfig
+    from connect4_amd.generation import run_generation
+    from connect4_amd.net import NetConfig
+    from connect4_amd.training import ModelConfig, Trainer
+    torch.manual_seed(50 + rank)      # the ranks' trainers start from DIFFERENT weights: only the broadcast can make them equal
+    tr = Trainer(ModelConfig(net_config=NetConfig(n_residuals=1), batch_size=64, n_training_epochs=1), device="cuda:0")
+    start = tr.state()
+    h0 = hashlib.sha256(b"".join(v.numpy().tobytes() for v in start["net_state_dict"].values())).hexdigest()
+    tr.broadcast_state(src=0)         # generation 0 is played by ONE net on every rank (as after a previous generation's broadcast)
+    out = []
+    for gen in range(2):
+        games, loss = run_generation(tr, MCTSConfig.self_play(16), n_games=26, save_dir=save_dir, gen=gen, seed=3, device=0, n_slots=16)
+        st = tr.state()
+        blob = b"".join(v.numpy().tobytes() for v in st["net_state_dict"].values())
+        blob += b"".join(ps["momentum_buffer"].numpy().tobytes() for ps in st["optimiser_state_dict"]["state"].values())
+        out.append((int(games.n_games), games.ids.tolist(), loss, hashlib.sha256(blob).hexdigest(), st["scheduler_state_dict"]["last_epoch"]))
+    q.put((rank, h0, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_generations_end_with_one_model(tmp_path):
+    """run_generation on two ranks (both on this card, gloo).  Every rank plays its shard and receives all
+    games; rank 0 trains and writes data.pth / net.pth; afterwards EVERY rank holds rank 0's net, batch-norm statistics and
+    momentum buffers bit for bit -- over two generations, so the second generation's shards are played by one net."""
+    import os
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_generation_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (r0, h0a, a), (r1, h0b, b) = outs
+    assert h0a != h0b                                   # they really started apart
+    for ga, gb in zip(a, b):
+        assert ga[0] == gb[0] == 26 and ga[1] == gb[1] == list(range(26))
+        assert ga[2] is not None and ga[2] == gb[2]     # the loss travels with the state
+        assert ga[3] == gb[3] and ga[4] == gb[4]        # net + momentum: identical bytes; same scheduler step
+    assert a[0][3] != a[1][3]                           # ... and training changed them between the generations
+    for gen in (0, 1):
+        assert os.path.exists(os.path.join(str(tmp_path), str(gen), "data.pth"))
+        ck = torch.load(os.path.join(str(tmp_path), str(gen), "net.pth"), weights_only=True)
+        assert set(ck) == {"net_state_dict", "optimiser_state_dict", "scheduler_state_dict"}
+
+
 def _rccl_worker(port, q):
     import os
     import torch

@@ -2539,15 +2539,17 @@ int c4_engine_create(const c4_config *cfg, int device, c4_engine **out)
         if (bits == 0 && cfg->eval_mode == C4_EVAL_EXTERNAL_F32 && !cfg->stop_after_move) {
             // The reference's table lives as long as its player and is shared by all its games
             // (evaluators.py:9-25), so positions of earlier games keep answering: size it for many
-            // games' worth of evaluations -- 128 x slots x simulations entries (2^29 = 25.8 GB for the 4096-game
-            // configuration; measured there: 2^25 227 M, 2^26 238, 2^27 245, 2^28 249, 2^29 252, 2^30 254 M
-            // expansions/s as the hit rate climbs from 74 % to 81 % and direct-mapped collisions thin out), at most
-            // 2^29 entries and a quarter of the free device memory (288 GB of HBM is there to be used).
-            const uint64_t want = 128ULL * (uint64_t)cfg->n_slots * ((uint64_t)cfg->simulations + 1);
+            // games' worth of evaluations -- 256 x slots x simulations entries (2^30 = 51.5 GB for the 4096-game
+            // configuration; measured there with the fp16 net in round 2: 2^25 227 M, 2^26 238, 2^27 245, 2^28 249, 2^29 252,
+            // 2^30 254 M expansions/s as the hit rate climbs from 74 % to 81 % and direct-mapped collisions thin out; with the
+            // reference-precision net in round 3, where a miss costs twice as much: 2^28 239 M, 2^29 245 M, 2^30 248 M), at most
+            // 2^30 entries and a quarter of the FREE device memory as it is after this engine's node pools are allocated (288 GB
+            // of HBM is there to be used; ranks that share a card in rehearsals each take a quarter of what they find).
+            const uint64_t want = 256ULL * (uint64_t)cfg->n_slots * ((uint64_t)cfg->simulations + 1);
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
             bits = 16;
-            while (bits < 29 && (1ULL << bits) < want && (sizeof(CacheEntry) << (bits + 1)) <= free_b / 4) ++bits;
+            while (bits < 30 && (1ULL << bits) < want && (sizeof(CacheEntry) << (bits + 1)) <= free_b / 4) ++bits;
         }
         if (bits > 0 && cfg->eval_mode == C4_EVAL_EXTERNAL_F32) {
             if (bits < 8 || bits > 30) { set_err(g_err, "eval_cache_log2_entries=%d out of range [8,30]", bits); c4_engine_destroy(e); *out = nullptr; return C4_EINVAL; }

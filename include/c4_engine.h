@@ -90,8 +90,8 @@ typedef struct {
                                           whose position was already answered is applied in place, no
                                           evaluator round trip.  Results are unchanged for a
                                           deterministic evaluator.  <0 off, 0 auto (on for self-play
-                                          with C4_EVAL_EXTERNAL_F32: 128 x n_slots x simulations entries
-                                          of 48 bytes, at most 2^29 and a quarter of the free device
+                                          with C4_EVAL_EXTERNAL_F32: 256 x n_slots x simulations entries
+                                          of 48 bytes, at most 2^30 and a quarter of the free device
                                           memory), else log2 of the table size */
     int32_t level_budget;              /* descent levels a slot may walk per launch; a descent that runs
                                           out is suspended and resumed by the next launch, so no launch

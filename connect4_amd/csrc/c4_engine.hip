@@ -591,12 +591,6 @@ __device__ __forceinline__ void publish_game(DevT &d, int g, long long gid, int 
 }
 
 // ---- evaluation cache ------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t mix64(uint64_t x)
-{
-    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
-    x ^= x >> 27; x *= 0x94D049BB133111EBULL;
-    return x ^ (x >> 31);
-}
 __device__ __forceinline__ uint64_t group_xor64(uint64_t v)
 {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
@@ -611,11 +605,18 @@ __device__ __forceinline__ CacheEntry *cache_slot(DevT &d, uint64_t key)
 {
     return d.cache + ((key * 0x9E3779B97F4A7C15ULL) >> (64 - d.cache_bits));
 }
-// check word over (key, value, prior[7]); lane k < 7 contributes prior[k], lane 7 the value
+// check word over (key, value, prior[7]); lane k < 7 contributes prior[k], lane 7 the value.  Its only job is to reject an entry
+// TORN by two concurrent writers (a key from one, payload words from the other): each lane's 32 payload bits, rotated by a
+// lane-specific amount inside a 64-bit word, xor-reduced over the group and xor-ed with the key.  A mixed entry passes only if the
+// xor of the differing lanes' (rotated) differences vanishes -- 2^-32 or less per tear, and tears need two writers on one
+// entry within nanoseconds.  (Until round 3 every lane hashed its word with two 64-bit multiplies: ~25 instructions per probe
+// and per insert on the tree waves' critical chain.)
 __device__ __forceinline__ uint64_t cache_check(uint64_t key, float value, float prior_lane, int lane)
 {
     const uint32_t bits = lane < 7 ? __float_as_uint(prior_lane) : __float_as_uint(value);
-    return key ^ group_xor64(mix64(((uint64_t)(lane + 1) << 32) | bits));
+    const uint64_t w = ((uint64_t)bits << 32) | (uint32_t)(bits * 0x9E3779B1u + (uint32_t)lane);
+    const int r = (lane * 7 + 3) & 63;
+    return key ^ group_xor64((w << r) | (w >> ((64 - r) & 63)));
 }
 template <class DevT>
 __device__ __forceinline__ bool cache_probe(DevT &d, uint64_t c0, uint64_t c1, int lane, float &value, float &prior_lane)

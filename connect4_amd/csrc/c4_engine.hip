@@ -673,6 +673,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                                           uint32_t *wg_stats = nullptr, const unsigned long long deadline = 0,
                                           uint32_t *req = nullptr, const int diag_stride = 0)
 {
+    (void)diag_stride;   // (diagnostic builds only: -DC4_SPLIT_PHASES=1)
     static_assert(!SPLIT || (WAVE_SYNC && LDS_STATE && PATH_KEPT), "the split kernel keeps slot states and paths in LDS");
     if (leaf_out && lane < 2) leaf_out[lane] = 0;
     if (g >= d.slot_hi) return;

@@ -887,7 +887,6 @@ __device__ __forceinline__ void net_forward_wave16q(const NetDev &nd, _Float16 *
     const int n = lane & 15, g = lane >> 4;
     auto stamp = [&](int i) { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); };
     stamp(0);
-    const int n_layers = 2 * nd.n_res;
     _Float16 *const p0h = buf, *const p0l = buf + PLANE16, *const p1h = buf + 2 * PLANE16, *const p1l = buf + 3 * PLANE16;
     const __amdgpu_buffer_rsrc_t wr = wq_rsrc(nd);
     const int voff = lane * 16;

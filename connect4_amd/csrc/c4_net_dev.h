@@ -826,6 +826,9 @@ __device__ __forceinline__ void store16p(const floatx4 &hi, const floatx4 &lo, _
 #ifndef C4_F32X3_PKEPI
 #define C4_F32X3_PKEPI 1
 #endif
+#ifndef C4_F32X3_MIXEPI
+#define C4_F32X3_MIXEPI 1
+#endif
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
@@ -862,9 +865,22 @@ __device__ __forceinline__ void store16q(const floatx4 &hi, const floatx4 &lo, _
         asm("v_max_f32 %0, %1, %2" : "=v"(y.x) : "v"(y.x), "v"(ly.x));
         asm("v_max_f32 %0, %1, %2" : "=v"(y.y) : "v"(y.y), "v"(ly.y));
         const half2v yh = __builtin_convertvector(y, half2v);
+#if C4_F32X3_MIXEPI
+        // lo = RN16((y - yh) * 2^11) as ONE mixed-precision fma per value: fma(yh [fp16 operand], -2^11, y * 2^11) is exact in
+        // float32 (y - yh has at most 13 significant bits), so the only rounding is the conversion -- the same value as the
+        // convert / subtract / scale / convert sequence, in 3 instructions per pair instead of 5
+        const float2v ysc = y * sc;
+        const uint32_t yhb = __builtin_bit_cast(uint32_t, yh);
+        const float nsc = -LO_SCALE;
+        uint32_t ylb;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ylb) : "v"(yhb), "s"(nsc), "v"(ysc.x));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(ylb) : "v"(yhb), "s"(nsc), "v"(ysc.y));
+        const half2v yl = __builtin_bit_cast(half2v, ylb);
+#else
         const float2v back = __builtin_convertvector(yh, float2v);
         const float2v rl = (y - back) * sc;
         const half2v yl = __builtin_convertvector(rl, half2v);
+#endif
         oh[2 * i] = yh.x; oh[2 * i + 1] = yh.y;
         ol[2 * i] = yl.x; ol[2 * i + 1] = yl.y;
     }

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("C4_ENGINE_LIB") or os.path.join(_HERE, "libc4engine.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "c4_engine.h")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OK, EINVAL, EDEVICE, ENOMEM, ESTATE, ECAPACITY = 0, -1, -2, -3, -4, -5
 RESULT_NONE, RESULT_XWIN, RESULT_DRAW, RESULT_OWIN = -1, 0, 1, 2
 EVAL_EXTERNAL_F32, EVAL_EXTERNAL_F64, EVAL_CENTRE = 0, 1, 2
@@ -120,6 +120,9 @@ SIGNATURES = {
     "c4_net_last_error": (C.c_char_p, []),
     "c4_selfplay_steps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "c4_net_debug_stamps": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
+    "c4_bn_workspace_floats": (C.c_longlong, [C.c_int, C.c_int]),
+    "c4_bn_train_forward": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_float] * 3 + [C.c_void_p]),
+    "c4_bn_train_backward": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
 }
 
 _lib = None

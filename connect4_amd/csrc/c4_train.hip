@@ -1,0 +1,243 @@
+// c4_train.hip -- the two kernels of the reference's train step that stock MIOpen spends half of it in: batch
+// normalisation in training mode, forward and backward, fused with the residual add and the LeakyReLU that follow it
+// in the reference's net (model.py:20-31 conv-bn-act, :36-55 residual block, :60-117 heads; the train step itself:
+// model.py:200-240).  float32 NCHW tensors [rows][channels][hw] (hw = 42), contiguous.
+//
+//   forward   y = act(bn(x) + residual),  bn(x) = (x - mean_c) * invstd_c * weight_c + bias_c,
+//             mean / biased variance over the first `valid_rows` rows (all rows but for the padded ragged batch of an
+//             epoch, net._BatchNorm2d), running statistics updated as torch.nn.BatchNorm2d does (momentum, unbiased
+//             variance), act = LeakyReLU(slope) (slope 1 = none);
+//   backward  dz = dy * (y > 0 ? 1 : slope);  dresidual = dz;  dbias = sum dz;  dweight = sum dz * xhat;
+//             dx = weight * invstd * (dz - dbias / M - xhat * dweight / M)  (rows beyond valid_rows: weight * invstd * dz).
+//
+// HBM bound: the forward reads x three times (sum, centred squares, apply: the two-pass variance keeps float32 at
+// the accuracy the reference's CPU kernels have) and writes y; the backward reads x, y, dy twice and writes dx
+// (+ dresidual).  One workgroup = one channel x one chunk of 64 rows; thread t owns (row t / hw, pixel t % hw) of six rows
+// at a time, so a wave reads whole 168-byte rows.  Every reduction is a fixed tree (threads -> wave -> block -> chunks
+// in float64): results are bit-reproducible from run to run.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/c4_engine.h"
+
+namespace {
+
+constexpr int TB = 256;            // threads per workgroup
+constexpr int ROWS_PER_CHUNK = 64;
+constexpr int MAX_CHUNKS = 1024;
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// sum over the workgroup, the same value in every thread (fixed order: lanes by butterfly, then waves 0..3)
+__device__ __forceinline__ float block_sum(float v, float *s4)
+{
+    v = wave_sum(v);
+    __syncthreads();               // s4 may still be read from the previous call
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((s4[0] + s4[1]) + s4[2]) + s4[3];
+}
+
+// total of a channel's per-chunk partials (float64, chunk order), the same value in every thread
+__device__ __forceinline__ double chunk_total(const float *part, int chunks, double *s1)
+{
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double a = 0.0;
+        for (int i = threadIdx.x; i < chunks; i += 64) a += (double)part[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+        if (threadIdx.x == 0) *s1 = a;
+    }
+    __syncthreads();
+    return *s1;
+}
+
+struct Geo {
+    int rows, valid_rows, channels, hw, chunks, rows_per_chunk;
+};
+
+// ws layout: [0] sums, [1] centred squares (forward) / [0] sum dz, [1] sum dz*xhat (backward): each [channels][chunks]
+__global__ __launch_bounds__(TB) void bn_sum_kernel(const float *__restrict__ x, float *__restrict__ ws, Geo g)
+{
+    __shared__ float s4[4];
+    const int c = blockIdx.x, ch = blockIdx.y;
+    const int rpb = TB / g.hw, tr = threadIdx.x / g.hw, p = threadIdx.x - tr * g.hw;
+    const int r0 = ch * g.rows_per_chunk, r1 = min(r0 + g.rows_per_chunk, g.valid_rows);
+    float a = 0.0f;
+    if (tr < rpb)
+        for (int r = r0 + tr; r < r1; r += rpb) a += x[((size_t)r * g.channels + c) * g.hw + p];
+    a = block_sum(a, s4);
+    if (threadIdx.x == 0) ws[(size_t)c * g.chunks + ch] = a;
+}
+
+__global__ __launch_bounds__(TB) void bn_var_kernel(const float *__restrict__ x, float *__restrict__ ws, Geo g)
+{
+    __shared__ float s4[4];
+    __shared__ double s1;
+    const int c = blockIdx.x, ch = blockIdx.y;
+    const double M = (double)g.valid_rows * g.hw;
+    const float mean = (float)(chunk_total(ws + (size_t)c * g.chunks, g.chunks, &s1) / M);
+    const int rpb = TB / g.hw, tr = threadIdx.x / g.hw, p = threadIdx.x - tr * g.hw;
+    const int r0 = ch * g.rows_per_chunk, r1 = min(r0 + g.rows_per_chunk, g.valid_rows);
+    float a = 0.0f;
+    if (tr < rpb)
+        for (int r = r0 + tr; r < r1; r += rpb) {
+            const float d = x[((size_t)r * g.channels + c) * g.hw + p] - mean;
+            a += d * d;
+        }
+    a = block_sum(a, s4);
+    if (threadIdx.x == 0) ws[(size_t)(g.channels + c) * g.chunks + ch] = a;
+}
+
+__global__ __launch_bounds__(TB) void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ res,
+                                                      const float *__restrict__ weight, const float *__restrict__ bias,
+                                                      float *running_mean, float *running_var, long long *nbt,
+                                                      float *__restrict__ y, float *save_mean, float *save_invstd,
+                                                      const float *__restrict__ ws, Geo g, float momentum, float eps, float slope)
+{
+    __shared__ double s1;
+    const int c = blockIdx.x, ch = blockIdx.y;
+    const double M = (double)g.valid_rows * g.hw;
+    const float mean = (float)(chunk_total(ws + (size_t)c * g.chunks, g.chunks, &s1) / M);
+    const double ss = chunk_total(ws + (size_t)(g.channels + c) * g.chunks, g.chunks, &s1);
+    const float var = (float)(ss / M);
+    const float invstd = 1.0f / sqrtf(var + eps);
+    if (ch == 0 && threadIdx.x == 0) {
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+        if (running_mean) {   // torch.nn.BatchNorm2d: running = (1 - momentum) * running + momentum * batch (unbiased variance)
+            const float unb = (float)(ss / (M - 1.0));
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unb;
+        }
+        if (nbt && c == 0) *nbt += 1;
+    }
+    const float w = weight[c], b = bias[c];
+    const int rpb = TB / g.hw, tr = threadIdx.x / g.hw, p = threadIdx.x - tr * g.hw;
+    const int r0 = ch * g.rows_per_chunk, r1 = min(r0 + g.rows_per_chunk, g.rows);
+    if (tr < rpb)
+        for (int r = r0 + tr; r < r1; r += rpb) {
+            const size_t i = ((size_t)r * g.channels + c) * g.hw + p;
+            float z = (x[i] - mean) * invstd * w + b;
+            if (res) z += res[i];
+            y[i] = z > 0.0f ? z : z * slope;
+        }
+}
+
+__global__ __launch_bounds__(TB) void bn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                           const float *__restrict__ dy, const float *__restrict__ save_mean,
+                                                           const float *__restrict__ save_invstd, float *__restrict__ ws, Geo g,
+                                                           float slope)
+{
+    __shared__ float s4[4];
+    const int c = blockIdx.x, ch = blockIdx.y;
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    const int rpb = TB / g.hw, tr = threadIdx.x / g.hw, p = threadIdx.x - tr * g.hw;
+    const int r0 = ch * g.rows_per_chunk, r1 = min(r0 + g.rows_per_chunk, g.valid_rows);
+    float a = 0.0f, bq = 0.0f;
+    if (tr < rpb)
+        for (int r = r0 + tr; r < r1; r += rpb) {
+            const size_t i = ((size_t)r * g.channels + c) * g.hw + p;
+            const float dz = y[i] > 0.0f ? dy[i] : dy[i] * slope;
+            a += dz;
+            bq += dz * ((x[i] - mean) * invstd);
+        }
+    a = block_sum(a, s4);
+    bq = block_sum(bq, s4);
+    if (threadIdx.x == 0) {
+        ws[(size_t)c * g.chunks + ch] = a;
+        ws[(size_t)(g.channels + c) * g.chunks + ch] = bq;
+    }
+}
+
+__global__ __launch_bounds__(TB) void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                          const float *__restrict__ dy, const float *__restrict__ weight,
+                                                          const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
+                                                          float *__restrict__ dx, float *__restrict__ dres, float *dweight, float *dbias,
+                                                          const float *__restrict__ ws, Geo g, float slope)
+{
+    __shared__ double s1;
+    const int c = blockIdx.x, ch = blockIdx.y;
+    const double M = (double)g.valid_rows * g.hw;
+    const double sdz = chunk_total(ws + (size_t)c * g.chunks, g.chunks, &s1);
+    const double sdzx = chunk_total(ws + (size_t)(g.channels + c) * g.chunks, g.chunks, &s1);
+    if (ch == 0 && threadIdx.x == 0) {
+        dbias[c] = (float)sdz;
+        dweight[c] = (float)sdzx;
+    }
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    const float k = weight[c] * invstd, mdz = (float)(sdz / M), mdzx = (float)(sdzx / M);
+    const int rpb = TB / g.hw, tr = threadIdx.x / g.hw, p = threadIdx.x - tr * g.hw;
+    const int r0 = ch * g.rows_per_chunk, r1 = min(r0 + g.rows_per_chunk, g.rows);
+    if (tr < rpb)
+        for (int r = r0 + tr; r < r1; r += rpb) {
+            const size_t i = ((size_t)r * g.channels + c) * g.hw + p;
+            const float dz = y[i] > 0.0f ? dy[i] : dy[i] * slope;
+            if (dres) dres[i] = dz;
+            const float xh = (x[i] - mean) * invstd;
+            dx[i] = r < g.valid_rows ? k * (dz - mdz - xh * mdzx) : k * dz;
+        }
+}
+
+bool make_geo(Geo &g, int rows, int valid_rows, int channels, int hw)
+{
+    if (rows <= 0 || channels <= 0 || hw <= 0 || hw > TB || valid_rows <= 0 || valid_rows > rows || (long long)valid_rows * hw < 2) return false;
+    g.rows = rows; g.valid_rows = valid_rows; g.channels = channels; g.hw = hw;
+    g.rows_per_chunk = ROWS_PER_CHUNK;
+    while ((rows + g.rows_per_chunk - 1) / g.rows_per_chunk > MAX_CHUNKS) g.rows_per_chunk *= 2;
+    g.chunks = (rows + g.rows_per_chunk - 1) / g.rows_per_chunk;
+    return channels <= 65535 && g.chunks <= 65535;
+}
+
+}  // namespace
+
+extern "C" {
+
+long long c4_bn_workspace_floats(int rows, int channels)
+{
+    Geo g;
+    if (!make_geo(g, rows, rows, channels, 1)) return C4_EINVAL;
+    return 2LL * channels * g.chunks;
+}
+
+int c4_bn_train_forward(const float *x_dev, const float *residual_dev, const float *weight_dev, const float *bias_dev,
+                        float *running_mean_dev, float *running_var_dev, long long *num_batches_tracked_dev, float *y_dev,
+                        float *save_mean_dev, float *save_invstd_dev, float *workspace_dev, int rows, int valid_rows, int channels,
+                        int hw, float momentum, float eps, float slope, void *hip_stream)
+{
+    Geo g;
+    if (!x_dev || !weight_dev || !bias_dev || !y_dev || !save_mean_dev || !save_invstd_dev || !workspace_dev || !make_geo(g, rows, valid_rows, channels, hw) ||
+        (running_mean_dev == nullptr) != (running_var_dev == nullptr))
+        return C4_EINVAL;
+    hipStream_t s = (hipStream_t)hip_stream;
+    const dim3 grid(channels, g.chunks);
+    bn_sum_kernel<<<grid, TB, 0, s>>>(x_dev, workspace_dev, g);
+    bn_var_kernel<<<grid, TB, 0, s>>>(x_dev, workspace_dev, g);
+    bn_apply_kernel<<<grid, TB, 0, s>>>(x_dev, residual_dev, weight_dev, bias_dev, running_mean_dev, running_var_dev, num_batches_tracked_dev, y_dev,
+                                        save_mean_dev, save_invstd_dev, workspace_dev, g, momentum, eps, slope);
+    return hipGetLastError() == hipSuccess ? C4_OK : C4_EDEVICE;
+}
+
+int c4_bn_train_backward(const float *x_dev, const float *y_dev, const float *dy_dev, const float *weight_dev, const float *save_mean_dev,
+                         const float *save_invstd_dev, float *dx_dev, float *dresidual_dev, float *dweight_dev, float *dbias_dev,
+                         float *workspace_dev, int rows, int valid_rows, int channels, int hw, float slope, void *hip_stream)
+{
+    Geo g;
+    if (!x_dev || !y_dev || !dy_dev || !weight_dev || !save_mean_dev || !save_invstd_dev || !dx_dev || !dweight_dev || !dbias_dev || !workspace_dev ||
+        !make_geo(g, rows, valid_rows, channels, hw))
+        return C4_EINVAL;
+    hipStream_t s = (hipStream_t)hip_stream;
+    const dim3 grid(channels, g.chunks);
+    bn_bwd_reduce_kernel<<<grid, TB, 0, s>>>(x_dev, y_dev, dy_dev, save_mean_dev, save_invstd_dev, workspace_dev, g, slope);
+    bn_bwd_apply_kernel<<<grid, TB, 0, s>>>(x_dev, y_dev, dy_dev, weight_dev, save_mean_dev, save_invstd_dev, dx_dev, dresidual_dev, dweight_dev, dbias_dev,
+                                            workspace_dev, g, slope);
+    return hipGetLastError() == hipSuccess ? C4_OK : C4_EDEVICE;
+}
+
+}  // extern "C"

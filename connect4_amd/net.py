@@ -34,14 +34,28 @@ class NetConfig:
 
 
 class _BatchNorm2d(nn.BatchNorm2d):
-    """nn.BatchNorm2d (same parameters and state-dict keys) that can take its batch statistics from the first
-    `valid_rows` samples only.  The trainer pads the ragged last batch of an epoch to the full batch size -- every
-    convolution then runs the shape MIOpen has already compiled kernels for instead of a new one per generation (6-9 s
-    each) -- and sets valid_rows: the padding rows are normalised with the real rows' statistics, carry no loss, and so
-    change neither the activations of the real rows nor any gradient."""
-    valid_rows = None
+    """nn.BatchNorm2d (same parameters and state-dict keys) with two additions for the train step on a GPU:
 
-    def forward(self, x):
+    * `forward(x, residual=None, slope=None)` = act(bn(x) + residual): in training mode on a CUDA float32 tensor this is ONE
+      pair of HIP kernels of the library (bn_train.fused_bn_act; stock MIOpen spends half of a train step in batch
+      normalisation at this net's shape), otherwise stock PyTorch operators in the reference's order (model.py:20-55);
+    * it can take its batch statistics from the first `valid_rows` samples only.  The trainer pads the ragged last batch of
+      an epoch to the full batch size -- every convolution then runs the shape MIOpen has already compiled kernels for
+      instead of a new one per generation (6-9 s each) -- and sets valid_rows: the padding rows are normalised with the
+      real rows' statistics, carry no loss, and so change neither the activations of the real rows nor any gradient."""
+    valid_rows = None
+    fused = True          # (False: stock operators on the GPU as well -- A/B runs and tests)
+
+    def forward(self, x, residual=None, slope=None):
+        if self.training and self.fused and x.is_cuda and x.dtype == torch.float32:
+            from .bn_train import fused_bn_act
+            return fused_bn_act(x, self, residual, 1.0 if slope is None else slope, self.valid_rows)
+        y = self._stock(x)
+        if residual is not None:
+            y = y + residual
+        return y if slope is None else F.leaky_relu(y, slope)
+
+    def _stock(self, x):
         k = self.valid_rows
         if k is None or not self.training:
             return super().forward(x)
@@ -57,9 +71,15 @@ class _BatchNorm2d(nn.BatchNorm2d):
         return y * self.weight.view(1, -1, 1, 1) + self.bias.view(1, -1, 1, 1)
 
 
+class _ConvBNAct(nn.Sequential):
+    """model.py:20-31: conv3x3 (no bias) + BN + LeakyReLU; indices 0/1/2 give the reference's key names."""
+
+    def forward(self, x):
+        return self[1](self[0](x), slope=self[2].negative_slope)
+
+
 def _conv_bn_act(cin, cout):
-    # model.py:20-31: conv3x3 (no bias) + BN + LeakyReLU; indices 0/1/2 give the key names
-    return nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1, bias=False), _BatchNorm2d(cout), nn.LeakyReLU(LEAK))
+    return _ConvBNAct(nn.Conv2d(cin, cout, 3, padding=1, bias=False), _BatchNorm2d(cout), nn.LeakyReLU(LEAK))
 
 
 class _Residual(nn.Module):
@@ -73,9 +93,8 @@ class _Residual(nn.Module):
         self.batch_norm2 = _BatchNorm2d(f)
 
     def forward(self, x):
-        y = F.leaky_relu(self.batch_norm1(self.conv1(x)), LEAK)
-        y = self.batch_norm2(self.conv2(y))
-        return F.leaky_relu(y + x, LEAK)
+        y = self.batch_norm1(self.conv1(x), slope=LEAK)
+        return self.batch_norm2(self.conv2(y), residual=x, slope=LEAK)
 
 
 class _ValueHead(nn.Module):
@@ -91,7 +110,7 @@ class _ValueHead(nn.Module):
         self.w2 = nn.Parameter(torch.tensor(0.5), requires_grad=False)
 
     def forward(self, x):
-        x = F.leaky_relu(self.batch_norm(self.conv1(x)), LEAK).flatten(1)
+        x = self.batch_norm(self.conv1(x), slope=LEAK).flatten(1)
         x = F.leaky_relu(self.fcN(x), LEAK)
         x = torch.tanh(self.fc1(x))
         return ((x + self.w1) * self.w2).view(-1)
@@ -107,7 +126,7 @@ class _PolicyHead(nn.Module):
         self.fc1 = nn.Linear(2 * AREA, WIDTH)
 
     def forward(self, x):
-        x = F.leaky_relu(self.batch_norm(self.conv1(x)), LEAK).flatten(1)
+        x = self.batch_norm(self.conv1(x), slope=LEAK).flatten(1)
         return torch.softmax(self.fc1(x), dim=1)
 
 

@@ -53,7 +53,8 @@ class Trainer:
     the reference's rule (cuda:0 when use_gpu and a GPU is there, model.py:143-147) -- a multi-rank caller
     passes its own GPU."""
 
-    def __init__(self, config: ModelConfig = None, file_name: str = None, device=None, pad_ragged_batches=None):
+    def __init__(self, config: ModelConfig = None, file_name: str = None, device=None, pad_ragged_batches=None,
+                 fused_bn=None, use_graph=None):
         self.config = config or ModelConfig()
         self.net = PolicyValueNet(self.config.net_config)
         if device is not None:
@@ -63,6 +64,18 @@ class Trainer:
         self.net.to(self.device)
         # the ragged last batch of an epoch is padded to the full batch size (see net._BatchNorm2d); on by default on a GPU
         self.pad_ragged_batches = (self.device.type == "cuda") if pad_ragged_batches is None else bool(pad_ragged_batches)
+        # On a GPU: batch normalisation (+ residual add + LeakyReLU) of the train step runs on the library's HIP kernels
+        # (bn_train.py), and the full batches of a train() call are ONE captured HIP graph replayed per batch -- a stock
+        # step is ~150 launches of ~25 us kernels, i.e. as much host dispatch as GPU work.  Both default on for cuda.
+        self.fused_bn = (self.device.type == "cuda") if fused_bn is None else bool(fused_bn)
+        self.use_graph = ((self.device.type == "cuda") if use_graph is None else bool(use_graph)) and self.fused_bn
+        # (no graph with stock batch normalisation: under capture MIOpen's batch-norm backward leaves a small non-zero mean in
+        #  dx, which is the whole gradient of the head convolutions' biases -- mathematically zero -- and they drift: -6.6
+        #  after 138 steps where the eager step leaves 0.02; measured, build/train_probe3.py of round 3)
+        from .net import _BatchNorm2d
+        for m in self.net.modules():
+            if isinstance(m, _BatchNorm2d):
+                m.fused = self.fused_bn
         self.optimiser = torch.optim.SGD(self.net.parameters(), lr=self.config.initial_lr,
                                          momentum=self.config.momentum, weight_decay=self.config.weight_decay)
         self.scheduler = MultiStepLR(self.optimiser, milestones=self.config.milestones, gamma=self.config.gamma)
@@ -80,31 +93,69 @@ class Trainer:
         values F32[N], priors F32[N,7]) -- tensors on any device; they are moved to the trainer's device once.
         Returns the last batch's loss."""
         n = int(boards.shape[0])
+        bs = self.config.batch_size
         boards, values, priors = boards.to(self.device), values.to(self.device), priors.to(self.device)
         self.net.train()
         last = None
+        graph = None            # the captured step of THIS call (the data tensors and the learning rate are baked into it)
+        eager_full = 0
+        want_graph = self.use_graph and self.device.type == "cuda" and (n // bs) * self.config.n_training_epochs >= 4
         for _ in range(self.config.n_training_epochs):
             perm = dataloader_permutation(n, generator).to(self.device)
-            for i in range(0, n, self.config.batch_size):
-                idx = perm[i:i + self.config.batch_size]
+            for i in range(0, n, bs):
+                idx = perm[i:i + bs]
                 k = int(idx.shape[0])
-                pad = self.pad_ragged_batches and k < self.config.batch_size and n > self.config.batch_size and k > 1
+                if k == bs and want_graph:
+                    if graph is None and eager_full >= 2:      # (the first steps run eagerly: momentum buffers, MIOpen's choices)
+                        graph, sidx, sloss = self._capture_step(boards, values, priors)
+                    if graph is not None:
+                        sidx.copy_(idx)
+                        graph.replay()
+                        last = sloss
+                        continue
+                    eager_full += 1
+                pad = self.pad_ragged_batches and k < bs and n > bs and k > 1
                 if pad:   # DataLoader's drop_last=False batch (model.py:208-212), at the full batch's shape
-                    idx = torch.cat([idx, idx[:1].expand(self.config.batch_size - k)])
+                    idx = torch.cat([idx, idx[:1].expand(bs - k)])
                     self._set_valid_rows(k)
-                b, v, p = boards[idx], values[idx], priors[idx]
-                self.optimiser.zero_grad()
-                xv, xp = self.net(b)
+                last = self._eager_step(boards[idx], values[idx], priors[idx], k if pad else None)
                 if pad:
-                    xv, xp, v, p = xv[:k], xp[:k], v[:k], p[:k]
                     self._set_valid_rows(None)
-                loss = self.value_loss(xv, v) + self.prior_loss(xp, p)   # model.py:221-225
-                loss.backward()
-                self.optimiser.step()
-                last = loss.detach()          # (read back once, after the last batch: no host synchronisation per step)
+        last = None if last is None else float(last)
+        del graph
+        self.optimiser.zero_grad()            # (gradients that live in a graph's pool are not kept)
         self.scheduler.step()       # once per generation (model.py:239)
         self.net.eval()
-        return None if last is None else float(last)
+        return last
+
+    def _eager_step(self, b, v, p, k=None):
+        """model.py:214-230 for one batch (its first k rows when the batch is a padded ragged one).  Returns the detached
+        loss (read back once, after the last batch: no host synchronisation per step); nothing of the step's autograd graph
+        outlives the call -- a graph captured later must not find AccumulateGrad nodes bound to this stream."""
+        self.optimiser.zero_grad()
+        xv, xp = self.net(b)
+        if k is not None:
+            xv, xp, v, p = xv[:k], xp[:k], v[:k], p[:k]
+        loss = self.value_loss(xv, v) + self.prior_loss(xp, p)   # model.py:221-225
+        loss.backward()
+        self.optimiser.step()
+        return loss.detach()
+
+    def _capture_step(self, boards, values, priors):
+        """One full-batch train step -- gather by a static index tensor, forward, loss, backward, SGD -- captured as a HIP
+        graph (torch.cuda.graph): replayed per batch with the batch's indices copied into `sidx`.  Same kernels, same order,
+        same arithmetic as the eager step."""
+        sidx = torch.zeros(self.config.batch_size, dtype=torch.int64, device=self.device)
+        graph = torch.cuda.CUDAGraph()
+        self.optimiser.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            b, v, p = boards[sidx], values[sidx], priors[sidx]
+            xv, xp = self.net(b)
+            loss = self.value_loss(xv, v) + self.prior_loss(xp, p)
+            loss.backward()
+            self.optimiser.step()
+            sloss = loss.detach()
+        return graph, sidx, sloss
 
     def state(self):
         """The checkpoint dict of save() with CPU tensors (model.py:242-250)."""

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define C4_ABI_VERSION 3
+#define C4_ABI_VERSION 4
 
 /* error codes */
 #define C4_OK 0
@@ -363,6 +363,27 @@ int c4_debug_fused_net_stamps(c4_engine *e, unsigned long long *out);
  * answered -> picked up by its tree wave} summed in units of 64 shader cycles, and the number of requests; needs
  * C4_TREE_STAMPS=1, else C4_ESTATE. */
 int c4_debug_latency_stamps(c4_engine *e, unsigned long long *out);
+
+/* ---- train step (the reference: ModelWrapper.train, neural/pytorch/model.py:200-240) ----------
+ * The convolutions, linear layers, losses and SGD of the train step are stock PyTorch-ROCm; batch normalisation in
+ * training mode -- half of a stock step's GPU time at this net's shape -- is the library's own, fused with the residual add
+ * and the LeakyReLU that follow it in the reference's net (model.py:20-31, 36-55, 60-117):
+ *     y = act(bn(x) + residual),   bn(x) = (x - mean_c) * invstd_c * weight_c + bias_c,   act = LeakyReLU(slope) (1 = none)
+ * float32, contiguous [rows][channels][hw] (NCHW, hw = 42).  Batch statistics (mean, biased variance; two passes) come from
+ * the first valid_rows rows (the trainer pads the ragged last batch of an epoch, connect4_amd/net.py:_BatchNorm2d);
+ * running_mean / running_var (may both be NULL) and *num_batches_tracked (may be NULL) are updated as torch.nn.BatchNorm2d
+ * updates them; save_mean / save_invstd [channels] are kept for the backward.  workspace: c4_bn_workspace_floats(rows,
+ * channels) floats.  Launches on hip_stream (capturable in a HIP graph); every reduction has a fixed order. */
+long long c4_bn_workspace_floats(int rows, int channels);
+int c4_bn_train_forward(const float *x_dev, const float *residual_dev, const float *weight_dev, const float *bias_dev,
+                        float *running_mean_dev, float *running_var_dev, long long *num_batches_tracked_dev, float *y_dev,
+                        float *save_mean_dev, float *save_invstd_dev, float *workspace_dev, int rows, int valid_rows, int channels,
+                        int hw, float momentum, float eps, float slope, void *hip_stream);
+/* dz = dy * (y > 0 ? 1 : slope); dresidual (may be NULL) = dz; dbias = sum dz; dweight = sum dz * xhat;
+ * dx = weight * invstd * (dz - dbias / M - xhat * dweight / M) over the valid rows (M = valid_rows * hw). */
+int c4_bn_train_backward(const float *x_dev, const float *y_dev, const float *dy_dev, const float *weight_dev, const float *save_mean_dev,
+                         const float *save_invstd_dev, float *dx_dev, float *dresidual_dev, float *dweight_dev, float *dbias_dev,
+                         float *workspace_dev, int rows, int valid_rows, int channels, int hw, float slope, void *hip_stream);
 
 int c4_abi_version(void);
 

@@ -29,9 +29,10 @@ class _FusedBNAct(torch.autograd.Function):
         save = torch.empty(2, ch, dtype=torch.float32, device=x.device)
         ws = torch.empty(int(lib.c4_bn_workspace_floats(rows, ch)), dtype=torch.float32, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        L.check(lib.c4_bn_train_forward(_ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
-                                        _ptr(num_batches_tracked), _ptr(y), save[0].data_ptr(), save[1].data_ptr(), _ptr(ws),
-                                        rows, k, ch, hw, float(momentum), float(eps), float(slope), stream))
+        with torch.cuda.device(x.device):       # the launch goes to the calling thread's current device
+            L.check(lib.c4_bn_train_forward(_ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                                            _ptr(num_batches_tracked), _ptr(y), save[0].data_ptr(), save[1].data_ptr(), _ptr(ws),
+                                            rows, k, ch, hw, float(momentum), float(eps), float(slope), stream))
         ctx.save_for_backward(x, y, weight, save)
         ctx.geo = (rows, k, ch, hw, float(slope), residual is not None)
         return y
@@ -47,8 +48,9 @@ class _FusedBNAct(torch.autograd.Function):
         dwb = torch.empty(2, ch, dtype=torch.float32, device=x.device)
         ws = torch.empty(int(lib.c4_bn_workspace_floats(rows, ch)), dtype=torch.float32, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        L.check(lib.c4_bn_train_backward(_ptr(x), _ptr(y), _ptr(dy), _ptr(weight), save[0].data_ptr(), save[1].data_ptr(), _ptr(dx), _ptr(dres),
-                                         dwb[0].data_ptr(), dwb[1].data_ptr(), _ptr(ws), rows, k, ch, hw, slope, stream))
+        with torch.cuda.device(x.device):
+            L.check(lib.c4_bn_train_backward(_ptr(x), _ptr(y), _ptr(dy), _ptr(weight), save[0].data_ptr(), save[1].data_ptr(), _ptr(dx), _ptr(dres),
+                                             dwb[0].data_ptr(), dwb[1].data_ptr(), _ptr(ws), rows, k, ch, hw, slope, stream))
         return dx, dwb[0], dwb[1], dres, None, None, None, None, None, None, None
 
 

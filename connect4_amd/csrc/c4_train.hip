@@ -10,8 +10,8 @@
 //   backward  dz = dy * (y > 0 ? 1 : slope);  dresidual = dz;  dbias = sum dz;  dweight = sum dz * xhat;
 //             dx = weight * invstd * (dz - dbias / M - xhat * dweight / M)  (rows beyond valid_rows: weight * invstd * dz).
 //
-// HBM bound: the forward reads x three times (sum, centred squares, apply: the two-pass variance keeps float32 at
-// the accuracy the reference's CPU kernels have) and writes y; the backward reads x, y, dy twice and writes dx
+// HBM bound: the forward reads x twice (statistics: a chunk's values stay in registers between its sum and its centred
+// squares, chunks are combined exactly in float64 -- the accuracy of a two-pass variance; apply) and writes y; the backward reads x, y, dy twice and writes dx
 // (+ dresidual).  One workgroup = one channel x one chunk of 64 rows; thread t owns (row t / hw, pixel t % hw) of six rows
 // at a time, so a wave reads whole 168-byte rows.  Every reduction is a fixed tree (threads -> wave -> block -> chunks
 // in float64): results are bit-reproducible from run to run.
@@ -60,6 +60,7 @@ __device__ __forceinline__ double chunk_total(const float *part, int chunks, dou
 
 struct Geo {
     int rows, valid_rows, channels, hw, chunks, rows_per_chunk;
+    int block_centred;   // forward: the workspace's squares are centred on each chunk's own mean (bn_stats_kernel)
 };
 
 // ws layout: [0] sums, [1] centred squares (forward) / [0] sum dz, [1] sum dz*xhat (backward): each [channels][chunks]
@@ -74,6 +75,44 @@ __global__ __launch_bounds__(TB) void bn_sum_kernel(const float *__restrict__ x,
         for (int r = r0 + tr; r < r1; r += rpb) a += x[((size_t)r * g.channels + c) * g.hw + p];
     a = block_sum(a, s4);
     if (threadIdx.x == 0) ws[(size_t)c * g.chunks + ch] = a;
+}
+
+// One read instead of two when a chunk's rows fit a thread's registers (64 rows: eleven values per thread): the workgroup's own
+// mean first, then the squares centred on IT from the registers; the chunks are combined exactly afterwards (stats_total):
+// sum_b (x - mean)^2 = M2_b + n_b (mean_b - mean)^2.
+constexpr int REG_MIN_RPB = 6, REG_VALUES = (ROWS_PER_CHUNK + REG_MIN_RPB - 1) / REG_MIN_RPB;   // hw <= 42: six rows at a time, eleven values
+__global__ __launch_bounds__(TB) void bn_stats_kernel(const float *__restrict__ x, float *__restrict__ ws, Geo g)
+{
+    __shared__ float s4[4];
+    const int c = blockIdx.x, ch = blockIdx.y;
+    const int rpb = TB / g.hw, tr = threadIdx.x / g.hw, p = threadIdx.x - tr * g.hw;
+    const int r0 = ch * g.rows_per_chunk, r1 = min(r0 + g.rows_per_chunk, g.valid_rows);
+    constexpr int MAXV = REG_VALUES;
+    float v[MAXV];
+    float a = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int r = r0 + tr + i * rpb;
+        const bool in = tr < rpb && r < r1;
+        v[i] = in ? x[((size_t)r * g.channels + c) * g.hw + p] : 0.0f;
+        a += v[i];
+    }
+    a = block_sum(a, s4);
+    const int nb = max(r1 - r0, 0) * g.hw;
+    const float mb = nb > 0 ? a / (float)nb : 0.0f;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int r = r0 + tr + i * rpb;
+        const bool in = tr < rpb && r < r1;
+        const float d = v[i] - mb;
+        q += in ? d * d : 0.0f;
+    }
+    q = block_sum(q, s4);
+    if (threadIdx.x == 0) {
+        ws[(size_t)c * g.chunks + ch] = a;
+        ws[(size_t)(g.channels + c) * g.chunks + ch] = q;
+    }
 }
 
 __global__ __launch_bounds__(TB) void bn_var_kernel(const float *__restrict__ x, float *__restrict__ ws, Geo g)
@@ -105,7 +144,25 @@ __global__ __launch_bounds__(TB) void bn_apply_kernel(const float *__restrict__ 
     const int c = blockIdx.x, ch = blockIdx.y;
     const double M = (double)g.valid_rows * g.hw;
     const float mean = (float)(chunk_total(ws + (size_t)c * g.chunks, g.chunks, &s1) / M);
-    const double ss = chunk_total(ws + (size_t)(g.channels + c) * g.chunks, g.chunks, &s1);
+    double ss = chunk_total(ws + (size_t)(g.channels + c) * g.chunks, g.chunks, &s1);
+    if (g.block_centred) {   // + sum_b n_b (mean_b - mean)^2, in float64 and chunk order
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            double a = 0.0;
+            for (int i = threadIdx.x; i < g.chunks; i += 64) {
+                const int nb = max(min((i + 1) * g.rows_per_chunk, g.valid_rows) - i * g.rows_per_chunk, 0) * g.hw;
+                if (nb > 0) {
+                    const double dm = (double)ws[(size_t)c * g.chunks + i] / nb - (double)mean;
+                    a += nb * dm * dm;
+                }
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+            if (threadIdx.x == 0) s1 = a;
+        }
+        __syncthreads();
+        ss += s1;
+    }
     const float var = (float)(ss / M);
     const float invstd = 1.0f / sqrtf(var + eps);
     if (ch == 0 && threadIdx.x == 0) {
@@ -188,7 +245,7 @@ __global__ __launch_bounds__(TB) void bn_bwd_apply_kernel(const float *__restric
 bool make_geo(Geo &g, int rows, int valid_rows, int channels, int hw)
 {
     if (rows <= 0 || channels <= 0 || hw <= 0 || hw > TB || valid_rows <= 0 || valid_rows > rows || (long long)valid_rows * hw < 2) return false;
-    g.rows = rows; g.valid_rows = valid_rows; g.channels = channels; g.hw = hw;
+    g.rows = rows; g.valid_rows = valid_rows; g.channels = channels; g.hw = hw; g.block_centred = 0;
     g.rows_per_chunk = ROWS_PER_CHUNK;
     while ((rows + g.rows_per_chunk - 1) / g.rows_per_chunk > MAX_CHUNKS) g.rows_per_chunk *= 2;
     g.chunks = (rows + g.rows_per_chunk - 1) / g.rows_per_chunk;
@@ -217,8 +274,13 @@ int c4_bn_train_forward(const float *x_dev, const float *residual_dev, const flo
         return C4_EINVAL;
     hipStream_t s = (hipStream_t)hip_stream;
     const dim3 grid(channels, g.chunks);
-    bn_sum_kernel<<<grid, TB, 0, s>>>(x_dev, workspace_dev, g);
-    bn_var_kernel<<<grid, TB, 0, s>>>(x_dev, workspace_dev, g);
+    if (g.rows_per_chunk == ROWS_PER_CHUNK && TB / hw >= REG_MIN_RPB) {   // one read of x for both statistics
+        g.block_centred = 1;
+        bn_stats_kernel<<<grid, TB, 0, s>>>(x_dev, workspace_dev, g);
+    } else {
+        bn_sum_kernel<<<grid, TB, 0, s>>>(x_dev, workspace_dev, g);
+        bn_var_kernel<<<grid, TB, 0, s>>>(x_dev, workspace_dev, g);
+    }
     bn_apply_kernel<<<grid, TB, 0, s>>>(x_dev, residual_dev, weight_dev, bias_dev, running_mean_dev, running_var_dev, num_batches_tracked_dev, y_dev,
                                         save_mean_dev, save_invstd_dev, workspace_dev, g, momentum, eps, slope);
     return hipGetLastError() == hipSuccess ? C4_OK : C4_EDEVICE;

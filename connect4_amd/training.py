@@ -92,6 +92,12 @@ class Trainer:
         """One generation (model.py:200-240): n_training_epochs shuffled passes over (boards F32[N,3,6,7],
         values F32[N], priors F32[N,7]) -- tensors on any device; they are moved to the trainer's device once.
         Returns the last batch's loss."""
+        if self.device.type == "cuda":
+            with torch.cuda.device(self.device):    # graph capture / replay and the library's launches go to the current device
+                return self._train(boards, values, priors, generator)
+        return self._train(boards, values, priors, generator)
+
+    def _train(self, boards, values, priors, generator):
         n = int(boards.shape[0])
         bs = self.config.batch_size
         boards, values, priors = boards.to(self.device), values.to(self.device), priors.to(self.device)
@@ -146,8 +152,8 @@ class Trainer:
         graph (torch.cuda.graph): replayed per batch with the batch's indices copied into `sidx`.  Same kernels, same order,
         same arithmetic as the eager step."""
         sidx = torch.zeros(self.config.batch_size, dtype=torch.int64, device=self.device)
-        graph = torch.cuda.CUDAGraph()
         self.optimiser.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             b, v, p = boards[sidx], values[sidx], priors[sidx]
             xv, xp = self.net(b)

@@ -66,11 +66,12 @@ def test_gpu_train_step_matches_reference_fixture(pad, fused_bn, use_graph):
 
 @pytest.mark.parametrize("rows,ch,valid,residual,slope", [(4096, 32, None, True, 0.01), (4096, 32, None, False, 0.01), (4096, 32, 1000, True, 0.01),
                                                            (300, 1, None, False, 0.01), (37, 2, 20, False, 0.01), (64, 32, None, False, None),
-                                                           (5000, 64, None, True, 0.2)])
+                                                           (5000, 64, None, True, 0.2), (70000, 2, None, False, 0.01)])
 def test_fused_batch_norm_kernels_against_float64_autograd(rows, ch, valid, residual, slope):
     """c4_bn_train_forward / c4_bn_train_backward (the library's HIP kernels behind net._BatchNorm2d on a GPU) against the
     same function written with stock operators in float64 (model.py:20-55: act(bn(x) + residual), batch statistics from
-    the valid rows): outputs, running statistics, and all four gradients.  Stated tolerance: 2e-5 relative to each
+    the valid rows): outputs, running statistics, and all four gradients (70,000 rows: chunks of 128 rows, the two-read statistics
+    kernels instead of the register-resident one).  Stated tolerance: 2e-5 relative to each
     tensor's largest entry (float32 kernels, fixed-order reductions, float64 across chunks)."""
     import torch.nn.functional as F
     from connect4_amd.bn_train import fused_bn_act

@@ -11,7 +11,7 @@ b = (torch.rand(n, 3, 6, 7, generator=g) > 0.7).float().cuda()
 v = torch.rand(n, generator=g).cuda()
 p = torch.softmax(torch.rand(n, 7, generator=g), 1).cuda()
 res = {}
-for tag, kw in (("stock eager", dict(fused_bn=False, use_graph=False)), ("stock graph", dict(fused_bn=False, use_graph=True)),
+for tag, kw in (("stock eager", dict(fused_bn=False, use_graph=False)),
                 ("fused eager", dict(fused_bn=True, use_graph=False)), ("fused graph", dict(fused_bn=True, use_graph=True))):
     torch.manual_seed(0)
     tr = Trainer(ModelConfig(n_training_epochs=2), device="cuda:0", **kw)
@@ -28,8 +28,3 @@ for tag, kw in (("stock eager", dict(fused_bn=False, use_graph=False)), ("stock 
 base = res["stock eager"]
 for tag in res:
     print("   %s vs stock eager: max |diff| %.3g" % (tag, max(float((base[k].double() - res[tag][k].double()).abs().max()) for k in base)))
-for tag in ("stock graph",):
-    d = sorted(((float((base[k].double() - res[tag][k].double()).abs().max()), k) for k in base), reverse=True)[:6]
-    print(tag, d)
-    for _, k in d[:3]:
-        print(k, base[k].flatten()[:4].tolist(), res[tag][k].flatten()[:4].tolist())

@@ -259,7 +259,7 @@ extern "C" {
 long long c4_bn_workspace_floats(int rows, int channels)
 {
     Geo g;
-    if (!make_geo(g, rows, rows, channels, 1)) return C4_EINVAL;
+    if (!make_geo(g, rows, rows, channels, 2)) return C4_EINVAL;   // (any hw >= 2: the workspace does not depend on it; one row is a valid batch)
     return 2LL * channels * g.chunks;
 }
 

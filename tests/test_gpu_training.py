@@ -66,12 +66,12 @@ def test_gpu_train_step_matches_reference_fixture(pad, fused_bn, use_graph):
 
 @pytest.mark.parametrize("rows,ch,valid,residual,slope", [(4096, 32, None, True, 0.01), (4096, 32, None, False, 0.01), (4096, 32, 1000, True, 0.01),
                                                            (300, 1, None, False, 0.01), (37, 2, 20, False, 0.01), (64, 32, None, False, None),
-                                                           (5000, 64, None, True, 0.2), (70000, 2, None, False, 0.01)])
+                                                           (5000, 64, None, True, 0.2), (70000, 2, None, False, 0.01), (1, 32, None, True, 0.01)])
 def test_fused_batch_norm_kernels_against_float64_autograd(rows, ch, valid, residual, slope):
     """c4_bn_train_forward / c4_bn_train_backward (the library's HIP kernels behind net._BatchNorm2d on a GPU) against the
     same function written with stock operators in float64 (model.py:20-55: act(bn(x) + residual), batch statistics from
     the valid rows): outputs, running statistics, and all four gradients (70,000 rows: chunks of 128 rows, the two-read statistics
-    kernels instead of the register-resident one).  Stated tolerance: 2e-5 relative to each
+    kernels instead of the register-resident one; one row: the ragged batch DataLoader(drop_last=False) may end an epoch with).  Stated tolerance: 2e-5 relative to each
     tensor's largest entry (float32 kernels, fixed-order reductions, float64 across chunks)."""
     import torch.nn.functional as F
     from connect4_amd.bn_train import fused_bn_act
@@ -140,3 +140,26 @@ def test_fused_batch_norm_is_reproducible_and_rejects_bad_shapes():
     args = [t.data_ptr(), None, s[0].data_ptr(), s[1].data_ptr(), None, None, None, t.data_ptr(), s[0].data_ptr(), s[1].data_ptr(), ws.data_ptr()]
     assert lib.c4_bn_train_forward(*args, 8, 9, 4, 42, 0.1, 1e-5, 1.0, None) == L.EINVAL       # valid_rows > rows
     assert lib.c4_bn_train_forward(*args, 8, 8, 4, 300, 0.1, 1e-5, 1.0, None) == L.EINVAL      # a row wider than a workgroup
+
+
+def test_gpu_trainer_one_row_ragged_batch_and_short_datasets():
+    """DataLoader(drop_last=False) may end an epoch with ONE position (model.py:208-212): it is trained on un-padded, through the
+    library's kernels; a dataset shorter than a batch, or with too few batches for a graph, runs eagerly.  Default GPU trainer
+    against the stock-operator trainer on the same shuffles: same weights to float32 accuracy."""
+    from connect4_amd.training import ModelConfig, Trainer
+    g = torch.Generator().manual_seed(11)
+    for n, bs, epochs in ((129, 64, 3), (40, 64, 2), (64 * 7 + 1, 64, 2)):
+        b = (torch.rand(n, 3, 6, 7, generator=g) > 0.6).float()
+        v = torch.rand(n, generator=g)
+        p = torch.softmax(torch.rand(n, 7, generator=g), 1)
+        sds = []
+        for kw in (dict(), dict(fused_bn=False, use_graph=False)):
+            torch.manual_seed(3)
+            tr = Trainer(ModelConfig(batch_size=bs, n_training_epochs=epochs), device="cuda", **kw)
+            torch.manual_seed(4)
+            loss = tr.train(b, v, p)
+            assert loss == loss
+            sds.append({k: x.detach().double().cpu() for k, x in tr.net.state_dict().items()})
+        assert int(sds[0]["body.0.1.num_batches_tracked"]) == int(sds[1]["body.0.1.num_batches_tracked"]) == epochs * -(-n // bs)
+        worst = max(float((sds[0][k] - sds[1][k]).abs().max()) for k in sds[0] if not k.endswith("conv1.bias"))
+        assert worst <= 2e-4, (n, worst)     # (the head convolutions' biases have a zero gradient in exact arithmetic: rounding noise only)

@@ -123,6 +123,8 @@ SIGNATURES = {
     "c4_bn_workspace_floats": (C.c_longlong, [C.c_int, C.c_int]),
     "c4_bn_train_forward": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_float] * 3 + [C.c_void_p]),
     "c4_bn_train_backward": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
+    "c4_conv3x3_wrw_workspace_floats": (C.c_longlong, []),
+    "c4_conv3x3_wrw": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
 }
 
 _lib = None

@@ -61,3 +61,40 @@ def fused_bn_act(x, bn, residual=None, slope=1.0, valid_rows=None):
     track = bn.track_running_stats and bn.running_mean is not None
     return _FusedBNAct.apply(x, bn.weight, bn.bias, residual, bn.running_mean if track else None, bn.running_var if track else None,
                              bn.num_batches_tracked if track else None, momentum, bn.eps, slope, valid_rows)
+
+
+class _Conv3x3(torch.autograd.Function):
+    """F.conv2d(x, weight, None, padding=1) for the tower's 3x3 convolutions (model.py:36-55) whose weight gradient is the
+    library's c4_conv3x3_wrw (one pass on the f32-input MFMA; MIOpen's pick is an NHWC implicit GEMM behind two layout
+    transposes).  Forward and the input gradient stay MIOpen's (Winograd)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.conv2d(x, weight, None, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            lib = L.load()
+            xc, dyc = x.contiguous(), dy.contiguous()
+            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            ws = torch.empty(int(lib.c4_conv3x3_wrw_workspace_floats()), dtype=torch.float32, device=x.device)
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            with torch.cuda.device(x.device):
+                L.check(lib.c4_conv3x3_wrw(_ptr(xc), _ptr(dyc), _ptr(dw), _ptr(ws), int(x.shape[0]), int(x.shape[1]), int(x.shape[2]), int(x.shape[3]), stream))
+        return dx, dw
+
+
+def conv3x3(conv, x, fused=True):
+    """conv(x) for an nn.Conv2d of the tower; the library's weight-gradient kernel behind it where it applies (CUDA float32,
+    32 -> 32 filters on the 6 x 7 board, gradients wanted), the module's own forward otherwise."""
+    w = conv.weight
+    if (fused and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and w.requires_grad and conv.bias is None
+            and tuple(w.shape) == (32, 32, 3, 3) and tuple(x.shape[1:]) == (32, 6, 7) and conv.padding == (1, 1) and conv.stride == (1, 1)):
+        return _Conv3x3.apply(x, w)
+    return conv(x)

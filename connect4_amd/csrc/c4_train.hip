@@ -303,3 +303,148 @@ int c4_bn_train_backward(const float *x_dev, const float *y_dev, const float *dy
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// c4_conv3x3_wrw: the weight gradient of the tower's convolutions (model.py:36-55: 3x3, 32 -> 32 filters, padding 1, no bias)
+//     dW[co][ci][ky][kx] = sum over rows n and pixels (y, x) of  dy[n][co][y][x] * x[n][ci][y + ky - 1][x + kx - 1]
+// float32 NCHW [rows][32][6][7], as autograd hands them over.  MIOpen's pick for this shape is an NHWC implicit GEMM
+// (46 us) behind two layout transposes (2 x 14 us) per layer; this is one pass over x and dy on the f32-input MFMA
+// (v_mfma_f32_32x32x2_f32: exact float32 products, fma chain): A = dy (32 couts x 2 pixels), B = x shifted by the tap
+// (2 pixels x 32 cins), nine accumulator tiles of 32 x 32 per wave, one per tap.  A wave stages one row (position) at a time
+// in LDS -- x zero-padded to 8 x 9 per channel so that a tap is an address offset -- while the next row's 10.7 KB are on
+// their way into registers; 21 pixel pairs x 9 taps = 189 MFMAs of 64 cycles per row, 4096 rows over 1024 waves: MFMA bound
+// at ~21 us.  Partials per workgroup, summed over workgroups in a fixed order by a second kernel: bit-reproducible.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+constexpr int WC = 32, WPIX = 42, WROW = WC * WPIX;          // channels, pixels, floats per row of a tensor
+constexpr int XSTRIDE = 73;                                    // floats per channel of the padded plane (8 x 9 = 72, +1: conflict-free across channels)
+constexpr int XPLANE = WC * XSTRIDE + 8;                       // floats of one wave's padded x
+constexpr int WRW_WAVES = 4;
+constexpr int WRW_F4 = WROW / 4;                               // 336 float4 per row: 5.25 per lane
+
+__global__ __launch_bounds__(WRW_WAVES * 64) void conv3x3_wrw_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                                             float *__restrict__ partial, int rows)
+{
+    __shared__ __attribute__((aligned(16))) float s_x[WRW_WAVES][XPLANE];
+    __shared__ __attribute__((aligned(16))) float s_dy[WRW_WAVES][WROW];
+    __shared__ float s_red[WRW_WAVES][1024];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave_id = blockIdx.x * WRW_WAVES + wv, n_waves = gridDim.x * WRW_WAVES;
+    float *const xs = s_x[wv];
+    float *const ds = s_dy[wv];
+    for (int i = lane; i < XPLANE; i += 64) xs[i] = 0.0f;     // the borders stay zero for the whole launch
+    // where this lane's six float4 of a row go in the padded plane (element e = ci * 42 + y * 7 + x -> ci * 73 + (y + 1) * 9 + x + 1)
+    int xoff[6][4];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = (lane + 64 * j) * 4 + q;
+            const int ci = e / WPIX, r = e - ci * WPIX, yy = r / 7, xx = r - yy * 7;
+            xoff[j][q] = ci * XSTRIDE + (yy + 1) * 9 + xx + 1;
+        }
+    floatx16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    const int co = lane & 31, kh = lane >> 5;     // this lane's operand row / column and which pixel of the pair
+    // a row's 336 float4 per tensor: six per lane, the sixth only for lanes 0..15 (the others re-read the row's last one and drop it)
+    float4 px0, px1, px2, px3, px4, px5, pd0, pd1, pd2, pd3, pd4, pd5;
+    const int last = lane < WRW_F4 - 320 ? lane + 320 : WRW_F4 - 1;
+#define C4_WRW_FETCH(N)                                                                                   \
+    do {                                                                                                  \
+        const float4 *gx = reinterpret_cast<const float4 *>(x + (size_t)(N) * WROW);                      \
+        const float4 *gd = reinterpret_cast<const float4 *>(dy + (size_t)(N) * WROW);                     \
+        px0 = gx[lane]; px1 = gx[lane + 64]; px2 = gx[lane + 128]; px3 = gx[lane + 192]; px4 = gx[lane + 256]; px5 = gx[last]; \
+        pd0 = gd[lane]; pd1 = gd[lane + 64]; pd2 = gd[lane + 128]; pd3 = gd[lane + 192]; pd4 = gd[lane + 256]; pd5 = gd[last]; \
+    } while (0)
+    int n = wave_id;
+    if (n < rows) C4_WRW_FETCH(n);
+    else { px0 = px1 = px2 = px3 = px4 = px5 = pd0 = pd1 = pd2 = pd3 = pd4 = pd5 = float4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    for (; n < rows; n += n_waves) {
+        // registers -> LDS (the previous row's reads are behind us: a wave's LDS operations execute in order)
+#define C4_WRW_STAGE(J, PX, PD)                                                                                     \
+    do {                                                                                                           \
+        xs[xoff[J][0]] = PX.x; xs[xoff[J][1]] = PX.y; xs[xoff[J][2]] = PX.z; xs[xoff[J][3]] = PX.w;                \
+        reinterpret_cast<float4 *>(ds)[lane + 64 * J] = PD;                                                        \
+    } while (0)
+        C4_WRW_STAGE(0, px0, pd0); C4_WRW_STAGE(1, px1, pd1); C4_WRW_STAGE(2, px2, pd2); C4_WRW_STAGE(3, px3, pd3); C4_WRW_STAGE(4, px4, pd4);
+        if (lane < WRW_F4 - 320) C4_WRW_STAGE(5, px5, pd5);
+        if (n + n_waves < rows) C4_WRW_FETCH(n + n_waves);   // the next row travels while this one is multiplied
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        int py = 0, pxx = kh;                                  // this lane's pixel of the current pair: (y, x), pixel index 2 p + kh
+#pragma unroll
+        for (int p = 0; p < WPIX / 2; ++p) {
+            const float a = ds[co * WPIX + 2 * p + kh];
+            const float *bp = xs + co * XSTRIDE + py * 9 + pxx;     // (the operand's column index is the input channel: same lane field)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[(t / 3) * 9 + (t % 3)], acc[t], 0, 0, 0);
+            pxx += 2;
+            if (pxx >= 7) { pxx -= 7; py += 1; }
+        }
+    }
+#undef C4_WRW_FETCH
+#undef C4_WRW_STAGE
+    // workgroup partial: tap by tap through LDS, waves summed in order
+    float *out = partial + (size_t)blockIdx.x * 9 * 1024;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_red[wv][((r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + co] = acc[t][r];     // [cout row][cin column]
+        __syncthreads();
+        for (int i = threadIdx.x; i < 1024; i += WRW_WAVES * 64) out[t * 1024 + i] = ((s_red[0][i] + s_red[1][i]) + s_red[2][i]) + s_red[3][i];
+    }
+}
+
+// dw = the partials summed in workgroup order: a block owns 32 outputs, eight threads per output take every eighth partial
+// (float64), then the eight are added in order
+__global__ __launch_bounds__(256) void conv3x3_wrw_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dw, int n_partials)
+{
+    __shared__ double s_part[8][32];
+    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + o;                        // = tap * 1024 + co * 32 + ci
+    double a = 0.0;
+    int w = sl;
+    for (; w + 56 < n_partials; w += 64) {       // eight loads in flight, added in partial order
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = partial[(size_t)(w + 8 * k) * 9 * 1024 + i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a += (double)v[k];
+    }
+    for (; w < n_partials; w += 8) a += (double)partial[(size_t)w * 9 * 1024 + i];
+    s_part[sl][o] = a;
+    __syncthreads();
+    if (sl == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += s_part[k][o];
+        const int tap = i >> 10, cc = i & 1023;
+        dw[cc * 9 + tap] = (float)t;                            // [co][ci][ky][kx]
+    }
+}
+
+constexpr int WRW_MAX_WGS = 256;
+
+}  // namespace
+
+extern "C" {
+
+long long c4_conv3x3_wrw_workspace_floats(void) { return (long long)WRW_MAX_WGS * 9 * 1024; }
+
+int c4_conv3x3_wrw(const float *x_dev, const float *dy_dev, float *dweight_dev, float *workspace_dev, int rows, int channels, int height, int width,
+                   void *hip_stream)
+{
+    if (!x_dev || !dy_dev || !dweight_dev || !workspace_dev || rows <= 0 || channels != WC || height != 6 || width != 7) return C4_EINVAL;
+    hipStream_t s = (hipStream_t)hip_stream;
+    const int wgs = rows >= WRW_MAX_WGS * WRW_WAVES ? WRW_MAX_WGS : (rows + WRW_WAVES - 1) / WRW_WAVES;
+    conv3x3_wrw_partial_kernel<<<wgs, WRW_WAVES * 64, 0, s>>>(x_dev, dy_dev, workspace_dev, rows);
+    conv3x3_wrw_reduce_kernel<<<9 * 1024 / 32, 256, 0, s>>>(workspace_dev, dweight_dev, wgs);
+    return hipGetLastError() == hipSuccess ? C4_OK : C4_EDEVICE;
+}
+
+}  // extern "C"

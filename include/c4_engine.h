@@ -385,6 +385,15 @@ int c4_bn_train_backward(const float *x_dev, const float *y_dev, const float *dy
                          const float *save_invstd_dev, float *dx_dev, float *dresidual_dev, float *dweight_dev, float *dbias_dev,
                          float *workspace_dev, int rows, int valid_rows, int channels, int hw, float slope, void *hip_stream);
 
+/* Weight gradient of the tower's convolutions (model.py:36-55: 3x3, 32 -> 32 filters, padding 1, no bias; the autograd backward of
+ * F.conv2d inside ModelWrapper.train, model.py:226): dweight[co][ci][ky][kx] = sum_n sum_yx dy[n][co][y][x] * x[n][ci][y+ky-1][x+kx-1],
+ * float32, contiguous NCHW [rows][32][6][7] (other shapes: C4_EINVAL -- the caller keeps PyTorch's own backward for them).  One pass
+ * over x and dy on the f32-input MFMA (exact float32 products), per-workgroup partials summed in a fixed order: reproducible.
+ * workspace: c4_conv3x3_wrw_workspace_floats() floats.  Launches on hip_stream (capturable). */
+long long c4_conv3x3_wrw_workspace_floats(void);
+int c4_conv3x3_wrw(const float *x_dev, const float *dy_dev, float *dweight_dev, float *workspace_dev, int rows, int channels, int height, int width,
+                   void *hip_stream);
+
 int c4_abi_version(void);
 
 #ifdef __cplusplus

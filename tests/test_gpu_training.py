@@ -163,3 +163,34 @@ def test_gpu_trainer_one_row_ragged_batch_and_short_datasets():
         assert int(sds[0]["body.0.1.num_batches_tracked"]) == int(sds[1]["body.0.1.num_batches_tracked"]) == epochs * -(-n // bs)
         worst = max(float((sds[0][k] - sds[1][k]).abs().max()) for k in sds[0] if not k.endswith("conv1.bias"))
         assert worst <= 2e-4, (n, worst)     # (the head convolutions' biases have a zero gradient in exact arithmetic: rounding noise only)
+
+
+@pytest.mark.parametrize("rows", [4096, 1, 37, 1030, 5000])
+def test_conv3x3_weight_gradient_kernel_against_float64(rows):
+    """c4_conv3x3_wrw (behind bn_train.conv3x3, the tower's convolutions in the GPU train step) against the weight gradient of
+    F.conv2d in float64; the input gradient and the forward stay MIOpen's and are compared with float64 too.  Stated
+    tolerance: 2e-5 of the largest entry (a float32 fma chain over rows x 42 products per weight)."""
+    import torch.nn.functional as F
+    from connect4_amd.bn_train import conv3x3
+    g = torch.Generator().manual_seed(rows)
+    conv = torch.nn.Conv2d(32, 32, 3, padding=1, bias=False).cuda()
+    x = torch.randn(rows, 32, 6, 7, generator=g).cuda().requires_grad_(True)
+    dy = torch.randn(rows, 32, 6, 7, generator=g).cuda()
+    y = conv3x3(conv, x)
+    assert type(y.grad_fn).__name__ == "_Conv3x3Backward"
+    y.backward(dy)
+    xd = x.detach().double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, None, 1, 1)
+    yd.backward(dy.double())
+    for a, b, what in ((y.detach(), yd.detach(), "y"), (x.grad, xd.grad, "dx"), (conv.weight.grad, wd.grad, "dweight")):
+        err = float((a.double() - b).abs().max()) / float(b.abs().max())
+        assert err <= 2e-5, (what, err)
+    # bit-reproducible
+    g1 = conv.weight.grad.clone()
+    conv.weight.grad = None
+    conv3x3(conv, x).backward(dy)
+    assert torch.equal(g1, conv.weight.grad)
+    # other shapes keep PyTorch's own backward
+    other = torch.nn.Conv2d(3, 32, 3, padding=1, bias=False).cuda()
+    assert type(conv3x3(other, torch.randn(4, 3, 6, 7, device="cuda")).grad_fn).__name__ != "_Conv3x3Backward"

@@ -86,6 +86,12 @@
                               // wave (games at a similar stage spend their iterations in similar phases: +1.6 % with the fp16 net, +0.3 % with the
                               // reference-precision net; sorting by simulations done or by the measured leaf depth: nothing); 0 = slot p -> wave p % TW
 #endif
+#ifndef C4_COOP_LEGAL
+#define C4_COOP_LEGAL 1      // the legal-move mask of a group's position by one lane per column + a ballot; the prior sum's seven fetches issued together
+#endif
+#ifndef C4_PICK_BPERM
+#define C4_PICK_BPERM 1      // the level loop's argmax: butterfly on the score alone + one fetch of the winner's record through the LDS crossbar
+#endif
 #ifndef C4_EARLY_REQUEST
 #define C4_EARLY_REQUEST 1   // software-pipelined level loop (tuning aid: -DC4_EARLY_REQUEST=0 restores the plain loop)
 #endif
@@ -394,6 +400,21 @@ __device__ __forceinline__ double ucb_score(double A, double B, uint32_t nc, dou
     return pf64 ? s64 : (double)s32;
 }
 
+// board.py:88-92 for a position all eight lanes of a group hold: lane c looks at column c (count based, as c4_board.h's legal_mask),
+// one ballot makes the mask -- 7 instructions where every lane computing all seven columns takes 40.  Call with the group's
+// lanes all active.
+__device__ __forceinline__ int legal_mask_group(uint64_t occ)
+{
+#if C4_COOP_LEGAL
+    const int lane = (int)(threadIdx.x & (GROUP - 1));
+    const bool legal = lane < WIDTH && col_count(occ, lane < WIDTH ? lane : 0) < HEIGHT;
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(legal);
+    return (int)((b >> (threadIdx.x & 63u & ~(uint32_t)(GROUP - 1))) & 0x7fu);
+#else
+    return legal_mask(occ);
+#endif
+}
+
 // argmax over the group on (score, k); ties -> larger k == higher column (tree.py:11-15).
 __device__ __forceinline__ int group_argmax(double s, int k)
 {
@@ -497,6 +518,34 @@ __device__ __forceinline__ void pick_step(double &s, int &k, uint32_t &n, uint32
 }
 #endif
 #undef C4_DPP_SELECT
+#if C4_PICK_BPERM
+// The argmax with the record moved ONCE: three butterfly steps on the score alone (v_max_f64 returns one of its operands: the
+// maximum is exact), the lanes that hold it found by one compare, the highest of them (ties -> higher column, tree.py:11-15)
+// by a count of leading zeros on the group's byte of the wave mask, and the winner's record fetched from its lane through the
+// LDS crossbar (four ds_bpermute_b32) -- 21 instructions where the butterfly with the record riding along takes 51.
+__device__ __forceinline__ void group_pick(Pick &a)
+{
+    double m = a.s, o;
+    o = dpp_f64<0xB1>(m);
+    asm("v_max_f64 %0, %1, %2" : "=v"(m) : "v"(m), "v"(o));
+    o = dpp_f64<0x4E>(m);
+    asm("v_max_f64 %0, %1, %2" : "=v"(m) : "v"(m), "v"(o));
+    o = dpp_f64<0x141>(m);
+    asm("v_max_f64 %0, %1, %2" : "=v"(m) : "v"(m), "v"(o));
+    const unsigned long long eq = __builtin_amdgcn_fcmp(a.s, m, 1 /* oeq */);
+    const int gb = (int)(threadIdx.x & 63u & ~(uint32_t)(GROUP - 1));
+    const uint32_t bits = (uint32_t)(eq >> gb) & 0xffu;
+    const int k = 31 - __builtin_clz(bits);
+    const int src = (gb + k) << 2;
+    const uint64_t wb = (uint64_t)__double_as_longlong(a.w);
+    const uint32_t wl = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)wb), wh = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(wb >> 32));
+    a.n = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)a.n);
+    a.info = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)a.info);
+    a.w = __longlong_as_double((long long)(((uint64_t)wh << 32) | wl));
+    a.k = k;
+    a.s = m;
+}
+#else
 __device__ __forceinline__ void group_pick(Pick &a)
 {
     const uint64_t wb = (uint64_t)__double_as_longlong(a.w);
@@ -516,6 +565,7 @@ __device__ __forceinline__ void group_pick(Pick &a)
 #endif
     a.w = __longlong_as_double((long long)(((uint64_t)wh << 32) | wl));
 }
+#endif
 
 // mcts.py:175-178: noise = Gamma(alpha, 1, size=7), zeroed on illegal columns and normalised (mcts.py:197-202)
 // with NumPy's sequential sum: a Dirichlet draw over the legal moves.  Lane k holds column k's raw draw.
@@ -827,7 +877,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             cached_answer = false;
             const uint64_t occ = leaf0 | leaf1;
             const int age = popc64(occ);
-            const int mask = legal_mask(occ);                    // tree.py:23 valid_moves (leaf is undecided)
+            const int mask = legal_mask_group(occ);              // tree.py:23 valid_moves (leaf is undecided)
             const bool legal = lane < 7 && ((mask >> lane) & 1);
             // mcts.py:197-202 normalise, in the prior's own dtype
             double prn;
@@ -835,8 +885,16 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             if (SCORE_F32) {
                 const float pf = legal ? (float)ev_prior : 0.0f;
                 float s = 0.0f;
+#if C4_COOP_LEGAL
+                float pall[7];   // (all seven fetches in flight before the first add: the sum keeps NumPy's order)
+#pragma unroll
+                for (int i = 0; i < 7; ++i) pall[i] = gshfl(pf, i);
+#pragma unroll
+                for (int i = 0; i < 7; ++i) s = s + pall[i];
+#else
 #pragma unroll
                 for (int i = 0; i < 7; ++i) s = s + gshfl(pf, i);
+#endif
                 prn = s > 0.0f ? (double)(pf / s) : (legal ? 1.0 / (double)__popc(mask) : 0.0);
                 pf64 = 0;
             } else {
@@ -1077,7 +1135,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             if (LDS_STATE) {
                 // the root record is implied by the slot state: N = completed simulations + 1 (mcts.py:132-134,
                 // :164-168), W is carried along, and its children are the first block of the fresh tree
-                cinfo = pack_info(GROUP, (uint32_t)__popc(legal_mask(root0 | root1)), ST_EVALUATED, 0,
+                cinfo = pack_info(GROUP, (uint32_t)__popc(legal_mask_group(root0 | root1)), ST_EVALUATED, 0,
                                   (!SCORE_F32 || d.use_noise) ? 1u : 0u);
                 cN = sims + 1;
                 cW = root_w;

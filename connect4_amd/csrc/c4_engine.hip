@@ -86,6 +86,9 @@
                               // wave (games at a similar stage spend their iterations in similar phases: +1.6 % with the fp16 net, +0.3 % with the
                               // reference-precision net; sorting by simulations done or by the measured leaf depth: nothing); 0 = slot p -> wave p % TW
 #endif
+#ifndef C4_ORIENTED_Q
+#define C4_ORIENTED_Q 1      // a record's q is stored from the point of view of the player who chooses AT ITS PARENT: the level loop reads the value it scores
+#endif
 #ifndef C4_COOP_LEGAL
 #define C4_COOP_LEGAL 1      // the legal-move mask of a group's position by one lane per column + a ballot; the prior sum's seven fetches issued together
 #endif
@@ -361,6 +364,20 @@ __device__ __forceinline__ double child_value_for(uint32_t status, uint32_t n, d
 #endif
     const double sv = side == 0 ? v : 1.0 - v;
     return (term || n > 0) ? sv : 0.0;
+}
+
+// C4_ORIENTED_Q: tree.py:27-44's value of a node "for the side to move at its parent" is what a record's q field holds -- the flip
+// 1 - v for an x-to-move parent is done once by whoever writes q (expansion, backup: same operation on the same float64, so the
+// same bits), an unvisited child's q is 0 and a terminal child's its exact result, flipped likewise: the level loop's
+// child_value_for (select by side, select by visited / terminal: eight instructions per level) becomes a plain read.
+__device__ __forceinline__ double orient_q(double v, int parent_side)
+{
+#if C4_ORIENTED_Q
+    return (parent_side & 1) ? 1.0 - v : v;
+#else
+    (void)parent_side;
+    return v;
+#endif
 }
 
 // mcts.py:147-161 ucb_score.  A = log(..)+pb_c_init and B = sqrt(Np) come from the host table.
@@ -930,26 +947,26 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                 const uint32_t cst = make_move(c0, c1, lane);
                 const uint32_t idx = base + k;
                 // q of a terminal child = its exact result (utils.py:19-22), see child_value_for
-                *pool.rec(idx) = Rec{0.0, cst >= ST_XWIN ? 0.5 * (double)(cst - ST_XWIN) : 0.0, prn, 0u, pack_info(0, 0, cst, bit, 0)};
+                *pool.rec(idx) = Rec{0.0, cst >= ST_XWIN ? orient_q(0.5 * (double)(cst - ST_XWIN), age) : 0.0, prn, 0u, pack_info(0, 0, cst, bit, 0)};
             }
             if (lane == 0) {   // mcts.py:132-134: position_value / search_value.add(value)
                 if (l1_valid && pdepth == 1) {   // the leaf is a child of the root: keep the LDS copy current
                     Rec &c = s_l1[gl][pend & 7];
                     c.n = 1;
                     c.w = ev_value;
-                    c.q = ev_value;
+                    c.q = orient_q(ev_value, age - 1);
                     c.info = pack_info(base, nchild, ST_EVALUATED, info_bit(pinfo), pf64);
                 }
                 pool.n(pend) = 1;
                 pool.w(pend) = ev_value;
-                pool.q(pend) = ev_value;
+                pool.q(pend) = orient_q(ev_value, age - 1);
                 pool.info(pend) = pack_info(base, nchild, ST_EVALUATED, info_bit(pinfo), pf64);
             }
             // mcts.py:164-168 backpropagate over the ancestors (values captured during the descent)
             {   // (a path is rarely longer than the group is wide: the first eight entries without a loop around them)
                 auto back_up = [&](uint32_t i) {
                     const PathEntry e = path_lds ? s_path[gl][i] : gpath[i];
-                    const double nw = e.w + ev_value, nq = div_normal(nw, (double)(e.n + 1));
+                    const double nw = e.w + ev_value, nq = orient_q(div_normal(nw, (double)(e.n + 1)), age + (int)pdepth + (int)i + 1);   // parent's side: (root age + i - 1) & 1
                     pool.n(e.node) = e.n + 1;
                     pool.w(e.node) = nw;
                     pool.q(e.node) = nq;
@@ -1031,7 +1048,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             const uint32_t ci = act ? pool.info(cb + lane) : 0;
             const int root_age = popc64(root0 | root1);
             const int side = root_age & 1;
-            const double V = act ? child_value_for(info_status(ci), cn, cq, side) : 0.0;
+            const double V = act ? (C4_ORIENTED_Q ? cq : child_value_for(info_status(ci), cn, cq, side)) : 0.0;
             // tree.py:104-109 + :139-147 values policy
             double vs = 0.0;
 #pragma unroll
@@ -1048,7 +1065,14 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             if (kb < 0) kb = group_argmax(act ? V : -1.0, act ? lane : -1);   // tree.py:69-73 best_move
             const uint32_t bi = gshfl(ci, kb);
             const uint32_t bn = gshfl(cn, kb);
+#if C4_ORIENTED_Q
+            // (the record's q is the value for the root's mover; the absolute value is value_sum / visit_count: the very division the
+            //  backups do, on the record's own w and n)
+            const double cw = act ? pool.w(cb + lane) : 0.0;
+            const double bq = div_normal(gshfl(cw, kb), (double)(bn > 0 ? bn : 1u));
+#else
             const double bq = gshfl(cq, kb);
+#endif
             const int mv = (int)info_move(bi);
             const uint32_t bst = info_status(bi);
             double absv;   // child.data.absolute_value (mcts.py:88)
@@ -1199,7 +1223,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                 lvl_wait += t1 - lvl_t0;
                 lvl_t0 = t1;
             }
-            const double V = child_value_for(info_status(inf), n, q, age & 1);
+            const double V = C4_ORIENTED_Q ? q : child_value_for(info_status(inf), n, q, age & 1);
 #if C4_SCORE_ALL
             // all eight lanes score (the lanes beyond the node's children hold records nobody reads otherwise): a select
             // instead of a branch around the division
@@ -1275,7 +1299,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                 lvl_wait += t1 - lvl_t0;
                 lvl_t0 = t1;
             }
-            const double V = child_value_for(info_status(inf), n, q, age & 1);
+            const double V = C4_ORIENTED_Q ? q : child_value_for(info_status(inf), n, q, age & 1);
             const double s = act ? ucb_score(A, B, n, p, V, pf64) : -std::numeric_limits<double>::infinity();
             Pick best{s, act ? lane : -1, n, inf, w};
             group_pick(best);                                   // mcts.py:141-142 max((score, child))
@@ -1334,7 +1358,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             {
                 auto back_up = [&](uint32_t i) {
                     const PathEntry e = s_path[gl][i];
-                    const double nw = e.w + value, nq = div_normal(nw, (double)(e.n + 1));
+                    const double nw = e.w + value, nq = orient_q(div_normal(nw, (double)(e.n + 1)), age + (int)depth + (int)i + 1);
                     pool.n(e.node) = e.n + 1;
                     pool.w(e.node) = nw;
                     pool.q(e.node) = nq;

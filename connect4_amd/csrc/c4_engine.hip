@@ -86,6 +86,9 @@
                               // wave (games at a similar stage spend their iterations in similar phases: +1.6 % with the fp16 net, +0.3 % with the
                               // reference-precision net; sorting by simulations done or by the measured leaf depth: nothing); 0 = slot p -> wave p % TW
 #endif
+#ifndef C4_VGPR_BASES
+#define C4_VGPR_BASES 1
+#endif
 #ifndef C4_ORIENTED_Q
 #define C4_ORIENTED_Q 1      // a record's q is stored from the point of view of the player who chooses AT ITS PARENT: the level loop reads the value it scores
 #endif
@@ -1209,6 +1212,13 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             r = Rec{};
             ab = double2{0.0, 0.0};
         }
+#if C4_VGPR_BASES
+        // the two bases of the level loop's requests in vector registers (the kernel has ~130 scalars spilled to lanes: four
+        // v_readlane per level otherwise)
+        const double2 *tab_v = d.tabAB;
+        const Rec *rec_v = pool.rec((uint32_t)lane);
+        asm volatile("" : "+v"(tab_v), "+v"(rec_v));
+#endif
         while (go) {
             if (BUDGET) levels_left -= 1;
             const uint32_t cb = info_base(cinfo), nc = info_nchild(cinfo), pf64 = info_pf64(cinfo);
@@ -1239,9 +1249,15 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             Rec rn = r;
             double2 abn = ab;
             if (go) {
+#if C4_VGPR_BASES
+                abn = tab_v[best.n];
+                asm volatile("" ::: "memory");
+                rn = rec_v[info_base(best.info)];
+#else
                 abn = d.tabAB[best.n];
                 asm volatile("" ::: "memory");
                 rn = *pool.rec(info_base(best.info) + lane);
+#endif
             }
             // ---- this level's bookkeeping
             cN = best.n;

@@ -86,6 +86,9 @@
                               // wave (games at a similar stage spend their iterations in similar phases: +1.6 % with the fp16 net, +0.3 % with the
                               // reference-precision net; sorting by simulations done or by the measured leaf depth: nothing); 0 = slot p -> wave p % TW
 #endif
+#ifndef C4_FILLERS
+#define C4_FILLERS (C4_ORIENTED_Q && C4_SCORE_ALL)   // a sibling block's unused records are written too, with q = -inf: they score -inf by arithmetic, the level loop needs no "is this lane a child" logic
+#endif
 #ifndef C4_VGPR_BASES
 #define C4_VGPR_BASES 1
 #endif
@@ -943,6 +946,23 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             const uint32_t nchild = (uint32_t)__popc(mask);
             const uint32_t base = nalloc * GROUP;
             nalloc += 1;
+#if C4_FILLERS
+            {   // all eight records of the block are written: the children in column order, then fillers nobody can choose -- their q
+                // is -inf, so their score (prior term + value, either form) is -inf by arithmetic
+                const int below = (1 << lane) - 1;
+                Rec nr{0.0, -std::numeric_limits<double>::infinity(), 0.0, 0u, pack_info(0, 0, ST_FRESH, 0, 0)};
+                uint32_t k = nchild + (uint32_t)__popc(~mask & 0x7f & below);
+                if (legal) {
+                    k = (uint32_t)__popc(mask & below);
+                    uint64_t c0 = leaf0, c1 = leaf1;
+                    const uint32_t bit = (uint32_t)(H1 * lane + col_count(occ, lane));
+                    const uint32_t cst = make_move(c0, c1, lane);
+                    // q of a terminal child = its exact result (utils.py:19-22), see child_value_for
+                    nr = Rec{0.0, cst >= ST_XWIN ? orient_q(0.5 * (double)(cst - ST_XWIN), age) : 0.0, prn, 0u, pack_info(0, 0, cst, bit, 0)};
+                }
+                *pool.rec(base + k) = nr;
+            }
+#else
             if (legal) {
                 const uint32_t k = (uint32_t)__popc(mask & ((1 << lane) - 1));
                 uint64_t c0 = leaf0, c1 = leaf1;
@@ -952,6 +972,7 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                 // q of a terminal child = its exact result (utils.py:19-22), see child_value_for
                 *pool.rec(idx) = Rec{0.0, cst >= ST_XWIN ? orient_q(0.5 * (double)(cst - ST_XWIN), age) : 0.0, prn, 0u, pack_info(0, 0, cst, bit, 0)};
             }
+#endif
             if (lane == 0) {   // mcts.py:132-134: position_value / search_value.add(value)
                 if (l1_valid && pdepth == 1) {   // the leaf is a child of the root: keep the LDS copy current
                     Rec &c = s_l1[gl][pend & 7];
@@ -1219,6 +1240,9 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
         const Rec *rec_v = pool.rec((uint32_t)lane);
         asm volatile("" : "+v"(tab_v), "+v"(rec_v));
 #endif
+#if C4_FILLERS
+        b1 ^= b0;   // inside the loop b1 is the occupancy: every stone goes in, only o's stones need a select
+#endif
         while (go) {
             if (BUDGET) levels_left -= 1;
             const uint32_t cb = info_base(cinfo), nc = info_nchild(cinfo), pf64 = info_pf64(cinfo);
@@ -1237,8 +1261,13 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
 #if C4_SCORE_ALL
             // all eight lanes score (the lanes beyond the node's children hold records nobody reads otherwise): a select
             // instead of a branch around the division
+#if C4_FILLERS
+            (void)act;
+            const double s = ucb_score(A, B, n, p, V, pf64);   // (a filler's q is -inf: so is its score)
+#else
             const double sc = ucb_score(A, B, act ? n : 0u, p, V, pf64);
             const double s = act ? sc : -std::numeric_limits<double>::infinity();
+#endif
 #else
             const double s = act ? ucb_score(A, B, n, p, V, pf64) : -std::numeric_limits<double>::infinity();
 #endif
@@ -1264,10 +1293,14 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
             cW = best.w;
             cinfo = best.info;
             cur = cb + (uint32_t)best.k;
-            {   // board.py:160-163 replayed: xor the recorded stone into the mover's colour
+            {   // board.py:160-163 replayed: xor the recorded stone into the mover's colour (b1 is kept as occupancy ^ b0 inside the loop)
                 const uint64_t stone = 1ULL << info_bit(cinfo);
                 b0 ^= (age & 1) ? 0ULL : stone;
+#if C4_FILLERS
+                b1 ^= stone;
+#else
                 b1 ^= (age & 1) ? stone : 0ULL;
+#endif
             }
             age += 1;
             depth += 1;
@@ -1285,6 +1318,9 @@ __device__ __forceinline__ void tree_step(DevT &d, const int g, const int lane, 
                 lvl_cnt += 1;
             }
         }
+#if C4_FILLERS
+        b1 ^= b0;
+#endif
 #else
         while (info_status(cinfo) == ST_EVALUATED && levels_left > 0) {
             levels_left -= 1;

@@ -2,7 +2,7 @@
 reference's net (oinkoink/neural/pytorch/model.py:20-31, 36-55, 60-117): a torch.autograd.Function over the library's
 c4_bn_train_forward / c4_bn_train_backward (connect4_amd/csrc/c4_train.hip).  Stock MIOpen spends half of a train
 step (model.py:200-240) in batch normalisation at this net's shape ([4096, 32, 6, 7]: 77 us forward, 134 us backward per
-layer); these kernels are HBM bound (~10 / ~20 us).  float32 NCHW, contiguous; no CPU path -- net._BatchNorm2d uses
+layer); these kernels are HBM bound (~23 / ~42 us).  float32 NCHW, contiguous; no CPU path -- net._BatchNorm2d uses
 this only for CUDA tensors in training mode and stock PyTorch otherwise.
 """
 import torch
